@@ -1,0 +1,85 @@
+"""Seeded synthetic Waymo-shaped scenes (no dataset, no network).
+
+Stands in for ``WaymoDataset.__getitem__`` (seg3d/datasets/waymo_dataset.py:281-336)
+on the bench / test path: produces the raw per-sample point rows the reference
+feeds to its voxelizer -- ``[x, y, z, time_lag(=0), tanh(intensity), elongation]``
+float32 (waymo_dataset.py:150-153) -- with the TOP-lidar geometry of
+tools/waymo_parser.py:14-15 (64 beams x 2650 azimuth columns).
+
+Geometry: sensor 2 m above a ground plane at z=0, beam inclinations uniformly
+spaced in [-17.6 deg, +2.4 deg]; each of 72 azimuth sectors has a vertical wall
+at distance U(8, 70) m; returns are the nearer of ground and wall, clipped at
+75 m, with N(0, 2 cm) range noise; ~10 k short-range "side lidar" points are
+added inside 20 m.  About 180 k points per scene.
+"""
+import numpy as np
+
+N_BEAMS = 64
+N_AZIMUTH = 2650
+SENSOR_HEIGHT = 2.0
+MAX_RANGE = 75.0
+
+
+def make_scene(seed, n_side=10000, dtype=np.float32):
+    """One sweep, rows [x, y, z, 0, tanh(intensity), elongation] (N, 6)."""
+    rs = np.random.RandomState(1000 + int(seed))
+    inc = np.deg2rad(np.linspace(-17.6, 2.4, N_BEAMS))
+    az = np.linspace(-np.pi, np.pi, N_AZIMUTH, endpoint=False)
+    az = az + rs.uniform(0, 2 * np.pi / N_AZIMUTH)
+    inc_g, az_g = np.meshgrid(inc, az, indexing="ij")
+
+    n_sector = 72
+    wall = rs.uniform(8.0, 70.0, size=n_sector)
+    sector = ((az_g + np.pi) / (2 * np.pi) * n_sector).astype(np.int64) % n_sector
+    d_wall = wall[sector] / np.cos(inc_g)  # slant range to the wall
+    with np.errstate(divide="ignore"):
+        d_ground = np.where(inc_g < 0, SENSOR_HEIGHT / np.sin(-inc_g), np.inf)
+    rng = np.minimum(d_wall, d_ground)
+    rng = rng + rs.normal(0.0, 0.02, size=rng.shape)
+    keep = (rng > 1.0) & (rng < MAX_RANGE)
+    # a few percent of beams give no return
+    keep &= rs.uniform(size=rng.shape) > 0.03
+    r, i_, a_ = rng[keep], inc_g[keep], az_g[keep]
+    xyz = np.stack([r * np.cos(i_) * np.cos(a_), r * np.cos(i_) * np.sin(a_),
+                    SENSOR_HEIGHT + r * np.sin(i_)], axis=1)
+
+    # side lidars / second returns: short range, wide vertical field of view
+    rs_r = rs.uniform(1.0, 20.0, size=n_side)
+    rs_a = rs.uniform(-np.pi, np.pi, size=n_side)
+    rs_z = np.abs(rs.normal(0.0, 0.6, size=n_side))
+    side = np.stack([rs_r * np.cos(rs_a), rs_r * np.sin(rs_a), rs_z], axis=1)
+    xyz = np.concatenate([xyz, side], axis=0)
+
+    n = xyz.shape[0]
+    feat = np.stack([np.zeros(n), np.tanh(rs.uniform(0, 1, size=n)), rs.uniform(0, 1, size=n)], axis=1)
+    return np.concatenate([xyz, feat], axis=1).astype(dtype)
+
+
+def cart2polar_rows(points):
+    """Cylinder-config input rows (waymo_dataset.py:270-273 with pointops_utils.py:8-11):
+    [rho, phi, z, x, y, feat3..5] -> (N, 8)."""
+    rho = np.sqrt(points[:, 0] ** 2 + points[:, 1] ** 2)
+    phi = np.arctan2(points[:, 1], points[:, 0])
+    polar = np.stack((rho, phi, points[:, 2]), axis=1)
+    return np.concatenate((polar, points[:, :2], points[:, 3:]), axis=1).astype(points.dtype)
+
+
+def make_small_scene(seed, n_points, extent=12.0, dtype=np.float32):
+    """Small clustered scene for parity tests: points on a few planes/blobs inside
+    +-extent metres so that windows at every stage hold several voxels."""
+    rs = np.random.RandomState(5000 + int(seed))
+    n_ground = n_points // 2
+    g = np.stack([rs.uniform(-extent, extent, n_ground), rs.uniform(-extent, extent, n_ground),
+                  rs.normal(0.0, 0.03, n_ground)], axis=1)
+    n_wall = n_points // 4
+    w = np.stack([rs.uniform(-extent, extent, n_wall), np.full(n_wall, 0.37 * extent) + rs.normal(0, 0.03, n_wall),
+                  rs.uniform(0.0, 3.0, n_wall)], axis=1)
+    n_blob = n_points - n_ground - n_wall
+    c = rs.uniform(-extent * 0.8, extent * 0.8, size=(6, 2))
+    which = rs.randint(0, 6, n_blob)
+    b = np.concatenate([c[which] + rs.normal(0, 0.5, (n_blob, 2)), np.abs(rs.normal(0.8, 0.5, (n_blob, 1)))], axis=1)
+    xyz = np.concatenate([g, w, b], axis=0)
+    xyz = xyz[rs.permutation(xyz.shape[0])]
+    n = xyz.shape[0]
+    feat = np.stack([np.zeros(n), np.tanh(rs.uniform(0, 1, size=n)), rs.uniform(0, 1, size=n)], axis=1)
+    return np.concatenate([xyz, feat], axis=1).astype(dtype)

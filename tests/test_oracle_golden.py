@@ -1,0 +1,107 @@
+"""Pins the CPU oracle against outputs of the reference's own Python
+(fixtures written by tests/golden/make_golden.py in the build container)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import index_ops, model, params
+from oracle import window as W
+
+import refcfg
+
+
+@pytest.mark.parametrize("tag,rng,vs", [("cart", refcfg.CART_RANGE, refcfg.CART_VOXEL),
+                                        ("cyl", refcfg.CYL_RANGE, refcfg.CYL_VOXEL)])
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_voxelize_matches_reference(golden_dir, tag, rng, vs, dt):
+    d = np.load(os.path.join(golden_dir, "voxelize.npz"))
+    k = f"{tag}_{dt}"
+    coors, ids = index_ops.voxelize(d[k + "_points"], vs, rng)
+    assert np.array_equal(coors, d[k + "_coors"])
+    assert np.array_equal(ids, d[k + "_ids"])
+    assert np.array_equal(index_ops.grid_size_of(vs, rng), d[tag + "_grid"])
+
+
+def test_voxelize_edge_cases():
+    vs, rng = refcfg.CART_VOXEL, refcfg.CART_RANGE
+    c, i = index_ops.voxelize(np.zeros((0, 6), np.float32), vs, rng)
+    assert c.shape == (0, 3) and i.shape == (0,)
+    p = np.array([[0, 0, 0, 0, 0, 0], [1e6, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [0.05, 0.05, 0.05, 0, 0, 0]], np.float32)
+    c, i = index_ops.voxelize(p, vs, rng)
+    assert i.tolist() == [0, -1, 0, 0] and c.tolist() == [[20, 720, 720]]
+
+
+def test_ingroup_rank_is_stable():
+    g = np.array([5, 3, 5, 5, 3, 9], np.int64)
+    assert index_ops.ingroup_rank(g).tolist() == [0, 0, 1, 2, 1, 0]
+
+
+@pytest.mark.parametrize("name", ["s1", "s2", "s4"])
+def test_window_partition_matches_reference(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, "window_partition.npz"))
+    st, c = int(d[name + "_stage"]), int(d[name + "_C"])
+    coords = torch.from_numpy(d[name + "_coords"])
+    info = W.window_partition(coords, refcfg.BATCHING_INFO[st], refcfg.WINDOW_SHAPE,
+                              refcfg.GRID_CART / (2 ** st), c)
+    for s in range(2):
+        assert np.array_equal(info[f"batch_win_inds_shift{s}"].numpy(), d[f"{name}_win{s}"])
+        assert np.array_equal(info[f"coors_in_win_shift{s}"].numpy(), d[f"{name}_inwin{s}"])
+        assert np.array_equal(info[f"voxel_batching_level_shift{s}"].numpy(), d[f"{name}_level{s}"])
+        inds = info[f"flat2win_inds_shift{s}"]
+        slot = np.full((coords.shape[0],), -1, np.int64)
+        for bl in range(4):
+            if bl in inds:
+                slot[inds[bl][1][0].numpy()] = inds[bl][0].numpy()
+                assert np.array_equal(info[f"key_mask_shift{s}"][bl].numpy(), d[f"{name}_mask{s}_l{bl}"])
+            else:
+                assert f"{name}_mask{s}_l{bl}" not in d
+        assert np.array_equal(slot, d[f"{name}_slot{s}"])
+        assert np.array_equal(info[f"pos_flat_shift{s}"].numpy(), d[f"{name}_pos{s}"])
+
+
+@pytest.mark.parametrize("name", ["c48", "c96"])
+def test_swformer_block_matches_reference(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, "swformer_block.npz"))
+    st, c, depth, seed = (int(v) for v in d[name + "_meta"])
+    coords, feats = torch.from_numpy(d[name + "_coords"]), torch.from_numpy(d[name + "_feats"])
+    info = W.window_partition(coords, refcfg.BATCHING_INFO[st], refcfg.WINDOW_SHAPE,
+                              refcfg.GRID_CART / (2 ** st), c)
+    p = params.state_dict_for(refcfg.swformer_param_shapes(c, depth), seed)
+    y = W.swformer_block(feats, info, p, "", depth, 8)
+    a0 = W.window_attention(feats, info["pos_dict_shift0"], info["flat2win_inds_shift0"],
+                            info["key_mask_shift0"], p, "layers.0.win_attn.", 8)
+    assert float((y - torch.from_numpy(d[name + "_out"])).abs().max()) <= 1e-5
+    assert float((a0 - torch.from_numpy(d[name + "_attn0"])).abs().max()) <= 1e-5
+
+
+def test_cosine_msa_matches_reference(golden_dir):
+    d = np.load(os.path.join(golden_dir, "cosine_msa.npz"))
+    t, w, c, h, seed = (int(v) for v in d["meta"])
+    p = params.state_dict_for({"in_proj_weight": (3 * c, c), "in_proj_bias": (3 * c,),
+                               "out_proj.weight": (c, c), "out_proj.bias": (c,), "tau": (1, 1, 1)}, seed)
+    p["tau"] = torch.full((1, 1, 1), 0.004)  # below tau_min: clamp path
+    q, v, pad = torch.from_numpy(d["q"]), torch.from_numpy(d["v"]), torch.from_numpy(d["pad"])
+    y = W.cosine_attention(q, q, v, p, "", h, pad)
+    assert float((y - torch.from_numpy(d["out"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("tag,rng,vs,dp", [("cart", refcfg.CART_RANGE, refcfg.CART_VOXEL, 6),
+                                           ("cyl", refcfg.CYL_RANGE, refcfg.CYL_VOXEL, 8)])
+def test_segformer_matches_reference_model_code(golden_dir, tag, rng, vs, dp):
+    """Oracle forward vs the reference's Segformer/PointTransformer code run on the oracle's
+    spconv/torch_scatter stand-ins (make_golden.gen_segformer)."""
+    keys = json.load(open(os.path.join(golden_dir, "segformer_keys.json")))
+    d = np.load(os.path.join(golden_dir, f"segformer_{tag}.npz"))
+    p = params.state_dict_for(refcfg.segformer_key_shapes(keys, dp), 0)
+    batch = {"points": torch.from_numpy(d["points"]), "voxel_coords": torch.from_numpy(d["voxel_coords"]),
+             "point_voxel_ids": torch.from_numpy(d["point_voxel_ids"]), "batch_size": int(d["batch_size"])}
+    cfg = {"grid_size": index_ops.grid_size_of(vs, rng), "batching_info": refcfg.BATCHING_INFO,
+           "window_shape": refcfg.WINDOW_SHAPE, "depths": refcfg.DEPTHS}
+    with torch.no_grad():
+        res = model.segformer_forward(batch, p, cfg)
+    for k in ("point_out", "voxel_out", "aux_voxel_out"):
+        assert float((res[k] - torch.from_numpy(d[k])).abs().max()) <= 1e-4, k
+    assert np.array_equal(res["aux_voxel_coords"].numpy(), d["aux_voxel_coords"])
