@@ -1,0 +1,224 @@
+/*
+ * seg3d_hip.h -- C ABI of libseg3d_hip.so, the MI355X (gfx950) implementation of the
+ * OpenSeg3D sparse-voxel segmentation hot path.
+ *
+ * Boundary: the reference exposes this path as Python callables
+ * backed by pybind11/CUDA extension modules and by the third-party spconv /
+ * torch_scatter packages.  This header is what a binding for that path binds instead:
+ * plain pointers and sizes, explicit stream, no torch types, no allocation inside
+ * (callers pass workspaces sized by the *_workspace_bytes queries), no exceptions.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises, so every entry point is hipGraph-capturable;
+ *   - return value: 0 = ok, <0 = SEG3D_E* below (checked before anything is enqueued);
+ *   - row-major, float32 features, int32 indices; -1 marks "none";
+ *   - coordinates are rows [batch, z, y, x] (spconv order), spatial shapes are (z, y, x);
+ *   - kernel offset k = (kz*3 + ky)*3 + kx, neighbour site = site + (kz-1, ky-1, kx-1).
+ *
+ * Each entry cites the reference interface (path:line under /root/reference) it replaces.
+ */
+#ifndef SEG3D_HIP_H
+#define SEG3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEG3D_OK 0
+#define SEG3D_EINVAL (-1)     /* bad argument (null pointer, unsupported size, ...) */
+#define SEG3D_EWORKSPACE (-2) /* workspace smaller than the *_workspace_bytes query */
+#define SEG3D_ELAUNCH (-3)    /* hipGetLastError() after a launch */
+
+#define SEG3D_REDUCE_SUM 0
+#define SEG3D_REDUCE_MEAN 1
+#define SEG3D_REDUCE_MAX 2
+
+/* ABI version; bumped whenever a signature below changes. */
+int seg3d_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * a2  VoxelGenerator.__init__  -- seg3d/core/voxel/voxel_generator.py:11-22
+ * grid = round((hi - lo) / voxel_size) evaluated in float32 (host helper, no GPU work).
+ * voxel_size: host float[3] (x,y,z); range: host float[6] (xyz min, xyz max); grid_xyz: host int32[3].
+ */
+int seg3d_grid_size(const float* voxel_size, const float* range, int32_t* grid_xyz);
+
+/* ------------------------------------------------------------------------------------------
+ * a1 + a4  points_to_voxel / _points_to_voxel_reverse_kernel -- voxel_generator.py:55-153,
+ *          batch id column + cumulative voxel-id offset of WaymoDataset.collate_batch --
+ *          seg3d/datasets/waymo_dataset.py:339-365.
+ * Hard voxelisation with first-seen voxel order, on device, for a whole collated batch:
+ * c_j = floor((p_j - lo_j) / vs_j) with an IEEE subtract and true divide in the dtype of
+ * `points`; a point is rejected (id -1) if any c_j is outside [0, grid_j).
+ *   points      [n, row_stride] row-major; xyz at columns xyz_col..xyz_col+2;
+ *               batch id (stored as a float, as the reference collates it) at batch_col, or
+ *               batch_col < 0 for a single sample (batch id 0)
+ *   voxel_size, range: host float[3], float[6]  (float32 constants, widened for the f64 entry)
+ *   voxel_coords      out [>= n, 4]  rows [b, z, y, x] in first-seen order
+ *   point_voxel_ids   out [n]        batch-global voxel row of each point, -1 if rejected
+ *   n_voxels          out device int32[1]
+ */
+size_t seg3d_voxelize_workspace_bytes(int64_t n_points);
+int seg3d_voxelize_f32(const float* points, int64_t n_points, int32_t row_stride, int32_t xyz_col,
+                       int32_t batch_col, const float* voxel_size, const float* range,
+                       int32_t* voxel_coords, int32_t* point_voxel_ids, int32_t* n_voxels,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int seg3d_voxelize_f64(const double* points, int64_t n_points, int32_t row_stride, int32_t xyz_col,
+                       int32_t batch_col, const float* voxel_size, const float* range,
+                       int32_t* voxel_coords, int32_t* point_voxel_ids, int32_t* n_voxels,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a14  ingroup_inds_ext.forward(group_inds, out_inds) -- seg3d/ops/ingroup_inds/src/
+ *      ingroup_inds.cpp:28-48, ingroup_inds_cuda.cu:12-25 (+ the CSR the callers rebuild from it).
+ * Rank of every element inside its group.  The reference hands ranks out in atomic arrival
+ * order; this build's canonical order is ascending element index (deterministic).
+ *   group_ids [n] in [0, n_groups), or -1 = not in any group
+ *   rank      out [n] or NULL   (-1 for skipped elements)
+ *   order     out [n] or NULL   element indices grouped by group id, ascending inside a group
+ *   offsets   out [n_groups+1] or NULL   CSR offsets into `order`
+ */
+size_t seg3d_group_index_workspace_bytes(int64_t n, int64_t n_groups);
+int seg3d_group_index(const int32_t* group_ids, int64_t n, int64_t n_groups, int32_t* rank,
+                      int32_t* order, int32_t* offsets, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a8-a11  spconv indice generation (third-party spconv, call sites seg3d/utils/spconv_utils.py:13-32,
+ *         seg3d/models/backbones/pointtransformer.py:26-34,73-81,159-166,184-189).
+ * Coordinate hash (open addressing, 64-bit linear site key -> row) and the neighbour tables
+ * ("rulebooks") built from it.  Tables are offset-major int32 [27][m_rows], -1 = inactive.
+ */
+size_t seg3d_coord_hash_bytes(int64_t m);
+int seg3d_coord_hash_build(const int32_t* coords, int64_t m, const int32_t* shape_zyx /*host[3]*/,
+                           void* table, size_t table_bytes, void* stream);
+/* SubMConv3d(k=3, padding=1): nbr[k][i] = row of the active site at coords[i] + offset(k). */
+int seg3d_rulebook_subm(const int32_t* coords, int64_t m, const int32_t* shape_zyx /*host[3]*/,
+                        const void* table, size_t table_bytes, int32_t* nbr, void* stream);
+/* SparseConv3d(k=3, stride=2, padding=1) output sites, ascending (b,z,y,x).
+ * shape_out = floor((shape_in + 2 - 3) / 2) + 1.  coords_out must hold cap_out >= min(8*m_in, cells) rows. */
+size_t seg3d_downsample_workspace_bytes(int32_t batch_size, const int32_t* shape_in_zyx /*host[3]*/);
+int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in, int32_t batch_size,
+                            const int32_t* shape_in_zyx /*host[3]*/, int32_t* coords_out,
+                            int64_t cap_out, int32_t* m_out /*device[1]*/, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* nbr_fwd[k][o] = fine row at 2*coords_out[o] + k - 1; nbr_inv[k][i] = coarse row o with
+ * 2*o + k - 1 == coords_in[i] (the table SparseInverseConv3d reuses under the same indice_key). */
+int seg3d_rulebook_strided(const int32_t* coords_out, int64_t m_out, int64_t m_in,
+                           const int32_t* shape_in_zyx /*host[3]*/, const void* table_in,
+                           size_t table_bytes, int32_t* nbr_fwd, int32_t* nbr_inv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a9-a11  spconv SubMConv3d / SparseConv3d / SparseInverseConv3d forward + backward
+ *         (same call sites as above).  One output-stationary gather-GEMM kernel serves all three:
+ *             y[r] = bias + sum_k x[nbr[k][r]] . W_k
+ *   weight      [cout, 27, cin]  (= [Cout,3,3,3,Cin], the layout the modules keep)
+ *   w_packed    [27 * cin * cout] floats, written by seg3d_spconv_pack_weight; cin/cout there are
+ *               those of `weight`; flags bit0: operand is W_k^T (dgrad), bit1: offsets reversed (k -> 26-k)
+ * dgrad: seg3d_spconv_fwd over the transposed pair list with a W^T pack and cin/cout swapped:
+ *        subm: same table, flags=3;  strided conv: the inverse table, flags=1;  inverse conv: the
+ *        forward table, flags=1.
+ * wgrad: dw[co][k][ci] = sum_r x[nbr[k][r]][ci] * dy[r][co].
+ * cin and cout must be multiples of 16 (cin multiple of 4 for fwd).
+ */
+int seg3d_spconv_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t flags,
+                             float* w_packed, void* stream);
+int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t m_in,
+                     const float* w_packed, const float* bias /*or NULL*/, int32_t cin, int32_t cout,
+                     float* y, void* stream);
+size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout);
+int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out,
+                       int64_t m_in, int32_t cin, int32_t cout, float* dw, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /
+ *      make_continuous_inds -- seg3d/utils/swformer_utils.py:8-31,108-171,
+ *      seg3d/models/layers/point_transformer_layer.py:71-87,141-149,209-220.
+ * One call per (stage, shift).  Window id = b*Wx*Wy*Wz + wx*(Wy*Wz) + wy*Wz + wz with
+ * w* = (c* + shift*) / win* (floor), in-window coordinate = (c* + shift*) % win*.
+ *   win_xyz, nwin_xyz, shift_xyz : host int32[3]  (nwin = ceil(S/win)+1, swformer_utils.py:119-121)
+ *   level_lo/level_hi/level_cap  : host int32[n_levels]  batching_range and max_tokens per level
+ * Outputs (each [m] unless noted; any of win_id..slot may be NULL):
+ *   win_id   batch_win_inds            in_win [m,3]  coors_in_win as (z,y,x)
+ *   rank     in-window rank (ascending voxel row)    level  batching level, -1 if no range matches
+ *   slot     flat2window index = compact_window_in_level * max_tokens + rank; -1 if rank >= max_tokens
+ *   tok      voxel rows grouped by window (ascending window id, ascending row inside)
+ *   win_start/win_count [<= min(m, canvas)]  CSR of the non-empty windows into tok
+ *   counts   device int32[2]: {number of non-empty windows, number of voxels with slot == -1}
+ */
+size_t seg3d_window_partition_workspace_bytes(int64_t m, int32_t batch_size, const int32_t* nwin_xyz);
+int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
+                           const int32_t* win_xyz, const int32_t* nwin_xyz, const int32_t* shift_xyz,
+                           int32_t n_levels, const int32_t* level_lo, const int32_t* level_hi,
+                           const int32_t* level_cap, int32_t* win_id, int32_t* in_win, int32_t* rank,
+                           int32_t* level, int32_t* slot, int32_t* tok, int32_t* win_start,
+                           int32_t* win_count, int32_t* counts, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* a17  SparseWindowPartitionLayer.get_pos_embed -- point_transformer_layer.py:151-203
+ * pos[i] = cat_{d in x,y,z} interleave(sin(v_d / f[0::2]), cos(v_d / f[1::2])), v_d = in_win_d - win_d/2,
+ * f = inv_freq [c/3] (device; the caller evaluates 1000**(2*(j//2)/(c/3)) exactly as torch does). */
+int seg3d_pos_embed(const int32_t* in_win, int64_t m, const int32_t* win_xyz /*host[3]*/,
+                    const float* inv_freq, int32_t c, float* pos, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a19-a21  flat2window -> CosineMultiheadAttention core -> window2flat --
+ *      swformer_utils.py:34-85, point_transformer_layer.py:233-258,
+ *      seg3d/models/layers/cosine_msa.py:115-177 (_scaled_cosine_attention).
+ * Variable-length (CSR) form: no padded [W,T,C] tensors are materialised.  For every window w,
+ * head h and query token i:  out_i = softmax_j( <q_i/|q_i|, k_j/|k_j|> / max(tau, tau_min) ) . v_j
+ * over the tokens j of the same window.  q, k, v are the in-projection outputs in flat voxel
+ * order with row strides ldq/ldk/ldv (floats); head h occupies columns [h*dh, (h+1)*dh).
+ *   out [m, heads*dh] flat voxel order (input of the out-projection); lse [m, heads] or NULL
+ *   (log-sum-exp per query row, kept for the backward).  m = number of voxel rows; dh in {6,12,24,48}
+ *   (8 heads on 48/96/192/384 channels, pointtransformer.py:141-157).
+ * Backward takes the forward's out and lse, returns gradients w.r.t. the raw q, k, v (through the
+ * normalisation) and adds the tau gradient into dtau[0] (caller zeroes it).
+ */
+size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t heads);
+int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
+                          int32_t ldv, const int32_t* tok, const int32_t* win_start,
+                          const int32_t* win_count, int64_t m, int32_t n_windows, int32_t heads,
+                          int32_t dh, const float* tau, float tau_min, float* out, float* lse,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
+                          int32_t ldv, const float* out, const float* dout, const float* lse,
+                          const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
+                          int64_t m, int32_t n_windows, int32_t heads, int32_t dh, const float* tau,
+                          float tau_min, float* dq, float* dk, float* dv, int32_t lddq, int32_t lddk,
+                          int32_t lddv, float* dtau, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a7, a25, a26  torch_scatter.scatter(src, index, dim=0, reduce='mean'|'max') at
+ *      seg3d/models/voxel_encoders/vfe.py:24-25, seg3d/models/layers/se_layer.py:24-28, and
+ *      voxel_pooling_ext.voxel_pooling_{forward,backward}_* -- seg3d/ops/voxel_pooling/src/
+ *      voxel_pooling.cpp:5-43, voxel_pooling_cuda.cu:10-79.
+ * Segmented reduce over a CSR (order, offsets) built by seg3d_group_index: deterministic, no
+ * float atomics.  Empty segments give 0.  argmax [n_seg, c] (MAX only, may be NULL) records the
+ * source row (first maximum in ascending row order), -1 for empty segments.
+ */
+int seg3d_segment_reduce_fwd(const float* x, int32_t c, const int32_t* order, const int32_t* offsets,
+                             int64_t n_seg, int32_t mode, float* out, int32_t* argmax, void* stream);
+/* dx [n, c] must be zero-filled by the caller for MAX; fully written for SUM/MEAN rows that belong
+ * to a segment (seg_of_row = group ids, -1 rows get 0). */
+int seg3d_segment_reduce_bwd(const float* dout, int32_t c, const int32_t* seg_of_row, int64_t n,
+                             const int32_t* offsets, const int32_t* argmax, int64_t n_seg,
+                             int32_t mode, float* dx, void* stream);
+
+/* a24  VoxelToPoint.__call__ -- seg3d/ops/voxel_to_point/voxel_to_point.py:4-17
+ * out[i] = feats[ids[i]] (zeros where ids[i] == -1).  Its backward is
+ * seg3d_segment_reduce_fwd(dout, SUM) over the CSR of ids. */
+int seg3d_gather_rows(const float* feats, const int32_t* ids, int64_t n, int32_t c, float* out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEG3D_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libseg3d_hip.so (the C ABI declared in include/seg3d_hip.h).
+
+There is no fallback: if the shared object is missing or a symbol does not resolve, loading
+raises.  Build it with ``python __graft_entry__.py`` (hipcc --offload-arch=gfx950).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libseg3d_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
+
+OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
+REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
+ABI_VERSION = 1
+
+_p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); must match include/seg3d_hip.h (tests/test_boundary.py cross-checks the names)
+SIGNATURES = {
+    "seg3d_abi_version": (ctypes.c_int, []),
+    "seg3d_grid_size": (ctypes.c_int, [_p, _p, _p]),
+    "seg3d_voxelize_workspace_bytes": (_sz, [_i64]),
+    "seg3d_voxelize_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "seg3d_voxelize_f64": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "seg3d_group_index_workspace_bytes": (_sz, [_i64, _i64]),
+    "seg3d_group_index": (ctypes.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "seg3d_coord_hash_bytes": (_sz, [_i64]),
+    "seg3d_coord_hash_build": (ctypes.c_int, [_p, _i64, _p, _p, _sz, _p]),
+    "seg3d_rulebook_subm": (ctypes.c_int, [_p, _i64, _p, _p, _sz, _p, _p]),
+    "seg3d_downsample_workspace_bytes": (_sz, [_i32, _p]),
+    "seg3d_downsample_coords": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _sz, _p]),
+    "seg3d_rulebook_strided": (ctypes.c_int, [_p, _i64, _i64, _p, _p, _sz, _p, _p, _p]),
+    "seg3d_spconv_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "seg3d_spconv_fwd": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "seg3d_spconv_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "seg3d_spconv_wgrad": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _sz, _p]),
+    "seg3d_window_partition_workspace_bytes": (_sz, [_i64, _i32, _p]),
+    "seg3d_window_partition": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p,
+                                              _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "seg3d_pos_embed": (ctypes.c_int, [_p, _i64, _p, _p, _i32, _p, _p]),
+    "seg3d_window_attn_workspace_bytes": (_sz, [_i64, _i32]),
+    "seg3d_window_attn_fwd": (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i32,
+                                             _p, _f, _p, _p, _p, _sz, _p]),
+    "seg3d_window_attn_bwd": (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32,
+                                             _i32, _i32, _p, _f, _p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    "seg3d_segment_reduce_fwd": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
+    "seg3d_segment_reduce_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _p]),
+    "seg3d_gather_rows": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+}
+
+_ERR = {EINVAL: "SEG3D_EINVAL (bad argument)", EWORKSPACE: "SEG3D_EWORKSPACE (workspace too small)",
+        ELAUNCH: "SEG3D_ELAUNCH (HIP launch/runtime error)"}
+
+_lib = None
+
+
+class Seg3dError(RuntimeError):
+    pass
+
+
+def header_symbols():
+    """Function names declared in include/seg3d_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(seg3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the shared object and bind every entry point; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Seg3dError(
+            f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
+            "Build it with `python __graft_entry__.py`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.seg3d_abi_version() != ABI_VERSION:
+        raise Seg3dError(f"libseg3d_hip.so ABI {lib.seg3d_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; negative return codes raise Seg3dError."""
+    rc = getattr(load(), name)(*args)
+    if rc != OK:
+        raise Seg3dError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def query(name, *args):
+    """Invoke a size_t-returning *_bytes query."""
+    return int(getattr(load(), name)(*args))

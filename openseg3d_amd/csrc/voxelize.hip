@@ -1,0 +1,205 @@
+// a1/a2/a4: hard voxelisation with first-seen voxel order, on device.
+// Reference: seg3d/core/voxel/voxel_generator.py:55-153 (serial numba loop over a dense 531 MB lookup grid).
+//
+// MI355X design: the dense grid is replaced by an open-addressing hash keyed on the linear cell
+// index.  Pass 1 inserts every in-range point and keeps, per cell, the smallest point index
+// (atomicMin) -- the point that would have created the voxel in the serial loop.  Lidar points
+// arrive in scan order, so neighbouring lanes very often hit the same cell: a wave ballot finds
+// the head lane of every run of equal keys and only heads touch the table.  Pass 2 flags the
+// creating points, an exclusive scan over the flags yields the first-seen rank, pass 3 writes
+// ids and coordinates.  HBM-bound integer work: N*(12 B read + 4 B write) + M*16 B algorithmic.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct VoxParams {
+    int32_t grid[3];  // x, y, z
+    int32_t row_stride, xyz_col, batch_col;
+};
+
+template <typename T>
+struct VoxConst {
+    T lo[3];
+    T vs[3];
+};
+
+__device__ __forceinline__ float floor_t(float v) { return floorf(v); }
+__device__ __forceinline__ double floor_t(double v) { return floor(v); }
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void vox_insert(const T* __restrict__ pts, int64_t n, VoxParams p,
+                                                       VoxConst<T> c, HashView h, uint32_t* __restrict__ slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool valid = i < n;
+    uint64_t key = 0;
+    if (valid) {
+        const T* row = pts + i * p.row_stride;
+        int32_t cc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // voxel_generator.py:139 -- subtract and TRUE divide in the point dtype, then floor
+            T v = floor_t((row[p.xyz_col + j] - c.lo[j]) / c.vs[j]);
+            if (v < (T)0 || v >= (T)p.grid[j]) valid = false;
+            cc[j] = (int32_t)v;
+        }
+        if (valid) {
+            int64_t b = p.batch_col >= 0 ? (int64_t)row[p.batch_col] : 0;
+            key = (uint64_t)(((b * p.grid[2] + cc[2]) * p.grid[1] + cc[1]) * (int64_t)p.grid[0] + cc[0]);
+        }
+    }
+    // head of a run of equal keys inside the wave (ascending point index => head has the run minimum)
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    const uint32_t plo = __shfl_up(klo, 1, SEG3D_WAVE), phi = __shfl_up(khi, 1, SEG3D_WAVE);
+    const int pvalid = __shfl_up((int)valid, 1, SEG3D_WAVE);
+    const bool head = valid && (lane == 0 || !pvalid || plo != klo || phi != khi);
+    const unsigned long long heads = __ballot(head);
+    uint32_t slot = 0xFFFFFFFFu;
+    if (head) {
+        slot = (uint32_t)hash_insert_slot(h, key);
+        atomicMin(&h.vals[slot], (int32_t)i);
+    }
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    int src = below ? 63 - __clzll((long long)below) : 0;
+    const uint32_t run_slot = __shfl(slot, src, SEG3D_WAVE);
+    if (i < n) slot_of[i] = valid ? run_slot : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(kThreads) void vox_flag(const uint32_t* __restrict__ slot_of, int64_t n, HashView h,
+                                                     uint32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = slot_of[i];
+    flag[i] = (s != 0xFFFFFFFFu && h.vals[s] == (int32_t)i) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kThreads) void vox_emit(const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ rank,
+                                                     int64_t n, HashView h, VoxParams p, int32_t* __restrict__ coords,
+                                                     int32_t* __restrict__ ids) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = slot_of[i];
+    if (s == 0xFFFFFFFFu) {
+        ids[i] = -1;
+        return;
+    }
+    const int32_t first = h.vals[s];
+    const int32_t id = (int32_t)rank[first];
+    ids[i] = id;
+    if (first == (int32_t)i) {
+        uint64_t key = h.keys[s];
+        const int32_t x = (int32_t)(key % (uint64_t)p.grid[0]); key /= (uint64_t)p.grid[0];
+        const int32_t y = (int32_t)(key % (uint64_t)p.grid[1]); key /= (uint64_t)p.grid[1];
+        const int32_t z = (int32_t)(key % (uint64_t)p.grid[2]); key /= (uint64_t)p.grid[2];
+        int4 row = make_int4((int32_t)key, z, y, x);
+        reinterpret_cast<int4*>(coords)[id] = row;
+    }
+}
+
+struct VoxWs {
+    void* table;
+    uint64_t cap;
+    uint32_t *slot_of, *flag, *rank, *tmp;
+};
+
+VoxWs carve(void* ws, int64_t n) {
+    WsCarver c(ws);
+    VoxWs w;
+    w.cap = hash_capacity(n);
+    w.table = c.take<char>(w.cap * 12);
+    w.slot_of = c.take<uint32_t>((size_t)n + 1);
+    w.flag = c.take<uint32_t>((size_t)n + 1);
+    w.rank = c.take<uint32_t>((size_t)n + 1);
+    w.tmp = c.take<uint32_t>(scan_tmp_count(n));
+    return w;
+}
+
+size_t ws_bytes(int64_t n) {
+    WsCarver c(nullptr);
+    const uint64_t cap = hash_capacity(n);
+    c.take<char>(cap * 12);
+    c.take<uint32_t>((size_t)n + 1);
+    c.take<uint32_t>((size_t)n + 1);
+    c.take<uint32_t>((size_t)n + 1);
+    c.take<uint32_t>(scan_tmp_count(n));
+    return c.off;
+}
+
+template <typename T>
+int voxelize_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_col, int32_t batch_col,
+                  const float* voxel_size, const float* range, int32_t* voxel_coords, int32_t* point_voxel_ids,
+                  int32_t* n_voxels, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || n >= (int64_t)0x7F000000 || !voxel_size || !range || !voxel_coords || !n_voxels || !workspace ||
+        row_stride < 3 || xyz_col < 0 || xyz_col + 3 > row_stride || batch_col >= row_stride)
+        return SEG3D_EINVAL;
+    if (n > 0 && (!points || !point_voxel_ids)) return SEG3D_EINVAL;
+    if (workspace_bytes < ws_bytes(n)) return SEG3D_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    VoxParams p;
+    if (seg3d_grid_size(voxel_size, range, p.grid) != SEG3D_OK) return SEG3D_EINVAL;
+    p.row_stride = row_stride;
+    p.xyz_col = xyz_col;
+    p.batch_col = batch_col;
+    VoxConst<T> c;
+    for (int j = 0; j < 3; ++j) {
+        c.lo[j] = (T)range[j];  // float32 constants widened exactly for the f64 entry
+        c.vs[j] = (T)voxel_size[j];
+    }
+    VoxWs w = carve(workspace, n);
+    HashView h = hash_view(w.table, w.cap);
+    if (hipMemsetAsync(h.keys, 0xFF, w.cap * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
+    if (hipMemsetAsync(h.vals, 0x7F, w.cap * 4, st) != hipSuccess) return SEG3D_ELAUNCH;
+    if (n == 0) {
+        if (hipMemsetAsync(n_voxels, 0, 4, st) != hipSuccess) return SEG3D_ELAUNCH;
+        return SEG3D_OK;
+    }
+    const unsigned nb = (unsigned)ceil_div64(n, kThreads);
+    hipLaunchKernelGGL(vox_insert<T>, dim3(nb), dim3(kThreads), 0, st, points, n, p, c, h, w.slot_of);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_flag, dim3(nb), dim3(kThreads), 0, st, w.slot_of, n, h, w.flag);
+    SEG3D_CHECK_LAUNCH();
+    int rc = scan_exclusive_u32(w.flag, w.rank, n, reinterpret_cast<uint32_t*>(n_voxels), w.tmp, st);
+    if (rc != SEG3D_OK) return rc;
+    hipLaunchKernelGGL(vox_emit, dim3(nb), dim3(kThreads), 0, st, w.slot_of, w.rank, n, h, p, voxel_coords,
+                       point_voxel_ids);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int seg3d_abi_version(void) { return 1; }
+
+int seg3d_grid_size(const float* voxel_size, const float* range, int32_t* grid_xyz) {
+    if (!voxel_size || !range || !grid_xyz) return SEG3D_EINVAL;
+    for (int j = 0; j < 3; ++j) {
+        // voxel_generator.py:15-18: float32 arrays, np.round (half to even)
+        volatile float span = range[3 + j] - range[j];
+        volatile float g = span / voxel_size[j];
+        grid_xyz[j] = (int32_t)__builtin_rintf(g);
+        if (grid_xyz[j] <= 0) return SEG3D_EINVAL;
+    }
+    return SEG3D_OK;
+}
+
+size_t seg3d_voxelize_workspace_bytes(int64_t n_points) { return ws_bytes(n_points < 0 ? 0 : n_points); }
+
+int seg3d_voxelize_f32(const float* points, int64_t n_points, int32_t row_stride, int32_t xyz_col, int32_t batch_col,
+                       const float* voxel_size, const float* range, int32_t* voxel_coords, int32_t* point_voxel_ids,
+                       int32_t* n_voxels, void* workspace, size_t workspace_bytes, void* stream) {
+    return voxelize_impl<float>(points, n_points, row_stride, xyz_col, batch_col, voxel_size, range, voxel_coords,
+                                point_voxel_ids, n_voxels, workspace, workspace_bytes, stream);
+}
+
+int seg3d_voxelize_f64(const double* points, int64_t n_points, int32_t row_stride, int32_t xyz_col, int32_t batch_col,
+                       const float* voxel_size, const float* range, int32_t* voxel_coords, int32_t* point_voxel_ids,
+                       int32_t* n_voxels, void* workspace, size_t workspace_bytes, void* stream) {
+    return voxelize_impl<double>(points, n_points, row_stride, xyz_col, batch_col, voxel_size, range, voxel_coords,
+                                 point_voxel_ids, n_voxels, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,409 @@
+"""Torch-facing wrappers of the C ABI (include/seg3d_hip.h): tensors in, tensors out.
+
+PyTorch is plumbing here -- device memory (caching allocator), the current HIP stream and
+autograd bookkeeping; all compute on this path happens in libseg3d_hip.so.  Every function
+requires CUDA(HIP) tensors and raises if the library is missing: there is no CPU fallback.
+
+The names exported for reference compatibility mirror ``seg3d.ops`` (seg3d/ops/__init__.py:1-6):
+``get_inner_win_inds``, ``voxel_to_point``, ``voxel_avg_pooling``, ``voxel_max_pooling``; plus
+``scatter`` with the ``torch_scatter.scatter(src, index, dim=0, reduce=...)`` signature used at
+vfe.py:25 and se_layer.py:25.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import REDUCE_MAX, REDUCE_MEAN, REDUCE_SUM
+
+_F3 = ctypes.c_float * 3
+_F6 = ctypes.c_float * 6
+_I3 = ctypes.c_int32 * 3
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.Seg3dError("openseg3d_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(nbytes, device):
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+
+
+def _i3(v):
+    return _I3(*[int(x) for x in v])
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _i32c(t):
+    return t.contiguous() if t.dtype == torch.int32 else t.to(torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ a1/a2/a4
+def grid_size(voxel_size, point_cloud_range):
+    """VoxelGenerator.__init__ grid (x, y, z) -- voxel_generator.py:15-18 (host helper)."""
+    out = _I3()
+    _lib.call("seg3d_grid_size", _F3(*[float(v) for v in voxel_size]),
+              _F6(*[float(v) for v in point_cloud_range]), out)
+    return [int(v) for v in out]
+
+
+def voxelize(points, voxel_size, point_cloud_range, xyz_col=0, batch_col=-1):
+    """Hard voxelisation of a (collated) point tensor on the GPU.
+
+    points: float32/float64 [N, D] CUDA.  Returns (voxel_coords int32 [M,4] as (b,z,y,x) in
+    first-seen order, point_voxel_ids int32 [N], -1 = out of range).  One host sync (reads M).
+    """
+    _need_gpu(points)
+    if points.dim() != 2 or points.dtype not in (torch.float32, torch.float64):
+        raise _lib.Seg3dError("points must be a float32/float64 [N, D] tensor")
+    points = points.contiguous()
+    n, d = points.shape
+    dev = points.device
+    coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+    ids = torch.empty((n,), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nbytes = _lib.query("seg3d_voxelize_workspace_bytes", n)
+    ws = _workspace(nbytes, dev)
+    fn = "seg3d_voxelize_f32" if points.dtype == torch.float32 else "seg3d_voxelize_f64"
+    _lib.call(fn, _ptr(points), n, d, int(xyz_col), int(batch_col), _F3(*[float(v) for v in voxel_size]),
+              _F6(*[float(v) for v in point_cloud_range]), _ptr(coords), _ptr(ids), _ptr(count), _ptr(ws),
+              ws.numel(), _stream())
+    m = int(count.item())
+    return coords[:m], ids
+
+
+# ------------------------------------------------------------------------------------------ a14
+def group_index(group_ids, n_groups, rank=True, order=True, offsets=True):
+    """Deterministic in-group rank and CSR of ``group_ids`` (int32 [n], -1 = skip)."""
+    _need_gpu(group_ids)
+    g = _i32c(group_ids)
+    n, dev = g.shape[0], g.device
+    r = torch.empty((n,), dtype=torch.int32, device=dev) if rank else None
+    o = torch.empty((n,), dtype=torch.int32, device=dev) if order else None
+    off = torch.empty((n_groups + 1,), dtype=torch.int32, device=dev) if offsets else None
+    ws = _workspace(_lib.query("seg3d_group_index_workspace_bytes", n, n_groups), dev)
+    _lib.call("seg3d_group_index", _ptr(g), n, int(n_groups), _ptr(r), _ptr(o), _ptr(off), _ptr(ws), ws.numel(),
+              _stream())
+    return r, o, off
+
+
+def get_inner_win_inds(group_inds):
+    """``seg3d.ops.get_inner_win_inds`` (ingroup_inds.py:7-20): int64 [N] -> int64 [N], non-differentiable.
+    Like the reference launcher (ingroup_inds.cpp:36) it reads max(group)+1 on the host."""
+    _need_gpu(group_inds)
+    if group_inds.numel() == 0:
+        return torch.zeros_like(group_inds)
+    ng = int(group_inds.max().item()) + 1
+    r, _, _ = group_index(group_inds.to(torch.int32), ng, rank=True, order=False, offsets=False)
+    return r.to(group_inds.dtype)
+
+
+class SegmentIndex:
+    """CSR of rows grouped by segment id (ids int32 [n], -1 = in no segment)."""
+
+    def __init__(self, ids, n_segments):
+        self.ids = _i32c(ids)
+        self.n_segments = int(n_segments)
+        _, self.order, self.offsets = group_index(self.ids, self.n_segments, rank=False)
+
+
+# ------------------------------------------------------------------------------------------ a8-a11 rulebooks
+class CoordHash:
+    def __init__(self, coords, spatial_shape):
+        _need_gpu(coords)
+        self.coords = _i32c(coords)
+        self.shape = [int(s) for s in spatial_shape]
+        m = self.coords.shape[0]
+        self.table = _workspace(_lib.query("seg3d_coord_hash_bytes", m), coords.device)
+        _lib.call("seg3d_coord_hash_build", _ptr(self.coords), m, _i3(self.shape), _ptr(self.table),
+                  self.table.numel(), _stream())
+
+
+def rulebook_subm(h):
+    m = h.coords.shape[0]
+    nbr = torch.empty((27, m), dtype=torch.int32, device=h.coords.device)
+    _lib.call("seg3d_rulebook_subm", _ptr(h.coords), m, _i3(h.shape), _ptr(h.table), h.table.numel(), _ptr(nbr),
+              _stream())
+    return nbr
+
+
+def downsample_coords(coords, batch_size, spatial_shape):
+    """Active sites of SparseConv3d(k=3, s=2, p=1), ascending (b,z,y,x).  One host sync (reads M_out)."""
+    _need_gpu(coords)
+    coords = _i32c(coords)
+    m, dev = coords.shape[0], coords.device
+    shape_out = [(int(s) + 2 - 3) // 2 + 1 for s in spatial_shape]
+    cells = int(batch_size) * shape_out[0] * shape_out[1] * shape_out[2]
+    cap = max(min(8 * m, cells), 1)
+    out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = _workspace(_lib.query("seg3d_downsample_workspace_bytes", int(batch_size), _i3(spatial_shape)), dev)
+    _lib.call("seg3d_downsample_coords", _ptr(coords), m, int(batch_size), _i3(spatial_shape), _ptr(out), cap,
+              _ptr(count), _ptr(ws), ws.numel(), _stream())
+    return out[: int(count.item())], shape_out
+
+
+def rulebook_strided(h_in, coords_out):
+    m_in, m_out = h_in.coords.shape[0], coords_out.shape[0]
+    dev = coords_out.device
+    fwd = torch.empty((27, m_out), dtype=torch.int32, device=dev)
+    inv = torch.empty((27, m_in), dtype=torch.int32, device=dev)
+    _lib.call("seg3d_rulebook_strided", _ptr(coords_out), m_out, m_in, _i3(h_in.shape), _ptr(h_in.table),
+              h_in.table.numel(), _ptr(fwd), _ptr(inv), _stream())
+    return fwd, inv
+
+
+# ------------------------------------------------------------------------------------------ a9-a11 conv
+PACK_FWD, PACK_T, PACK_T_FLIP = 0, 1, 3
+
+
+def pack_weight(weight, flags):
+    """weight [Cout,3,3,3,Cin] (or [Cout,27,Cin]) -> MFMA B-fragment stream for seg3d_spconv_fwd."""
+    w = _f32c(weight)
+    cout, cin = w.shape[0], w.shape[-1]
+    out = torch.empty((27 * cin * cout,), dtype=torch.float32, device=w.device)
+    _lib.call("seg3d_spconv_pack_weight", _ptr(w), cin, cout, int(flags), _ptr(out), _stream())
+    return out
+
+
+def _conv_apply(x, nbr, w_packed, bias, cin, cout):
+    m_out = nbr.shape[1]
+    y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
+    _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(w_packed), _ptr(bias), cin, cout,
+              _ptr(y), _stream())
+    return y
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """y[r] = bias + sum_k x[nbr[k][r]] . W_k ; nbr_t is the same pair list keyed by input row."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nbr, nbr_t, t_flags, packed):
+        x = _f32c(x)
+        cout, cin = weight.shape[0], weight.shape[-1]
+        if packed is None:
+            packed = pack_weight(weight, PACK_FWD)
+        y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout)
+        ctx.save_for_backward(x, weight)
+        ctx.nbr, ctx.nbr_t, ctx.t_flags, ctx.has_bias = nbr, nbr_t, t_flags, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32c(dy)
+        cout, cin = weight.shape[0], weight.shape[-1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = pack_weight(weight, ctx.t_flags)
+            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, dtype=torch.float32)
+            _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
+                      _ptr(dw), None, 0, _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None, None, None, None
+
+
+def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None):
+    _need_gpu(x, weight, nbr)
+    return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed)
+
+
+# ------------------------------------------------------------------------------------------ a13-a18 windows
+class WindowIndex:
+    """Outputs of seg3d_window_partition for one (stage, shift)."""
+    __slots__ = ("win_id", "in_win", "rank", "level", "slot", "tok", "win_start", "win_count", "counts",
+                 "n_windows", "n_dropped", "m")
+
+
+def window_partition(coords, batch_size, window_shape, nwin_xyz, shift_xyz, levels, want_debug=False):
+    """levels: list of (lo, hi, max_tokens).  No host sync: n_windows is bounded by min(m, canvas) and the
+    exact count stays on the device in ``counts`` until ``finish_window_index`` reads it."""
+    _need_gpu(coords)
+    coords = _i32c(coords)
+    m, dev = coords.shape[0], coords.device
+    canvas = int(batch_size) * int(nwin_xyz[0]) * int(nwin_xyz[1]) * int(nwin_xyz[2])
+    cap = max(min(m, canvas), 1)
+    wi = WindowIndex()
+    wi.m = m
+    i32 = dict(dtype=torch.int32, device=dev)
+    wi.in_win = torch.empty((m, 3), **i32)
+    wi.win_id = torch.empty((m,), **i32) if want_debug else None
+    wi.rank = torch.empty((m,), **i32) if want_debug else None
+    wi.level = torch.empty((m,), **i32) if want_debug else None
+    wi.slot = torch.empty((m,), **i32) if want_debug else None
+    wi.tok = torch.empty((max(m, 1),), **i32)
+    wi.win_start = torch.empty((cap,), **i32)
+    wi.win_count = torch.empty((cap,), **i32)
+    wi.counts = torch.zeros((2,), **i32)
+    nl = len(levels)
+    arr = ctypes.c_int32 * nl
+    lo, hi, capt = arr(*[int(l[0]) for l in levels]), arr(*[int(l[1]) for l in levels]), arr(*[int(l[2]) for l in levels])
+    ws = _workspace(_lib.query("seg3d_window_partition_workspace_bytes", m, int(batch_size), _i3(nwin_xyz)), dev)
+    _lib.call("seg3d_window_partition", _ptr(coords), m, int(batch_size), _i3(window_shape), _i3(nwin_xyz),
+              _i3(shift_xyz), nl, lo, hi, capt, _ptr(wi.win_id), _ptr(wi.in_win), _ptr(wi.rank), _ptr(wi.level),
+              _ptr(wi.slot), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.counts), _ptr(ws),
+              ws.numel(), _stream())
+    wi.n_windows = None
+    wi.n_dropped = None
+    return wi
+
+
+def pos_embed(in_win, window_shape, inv_freq, c):
+    m = in_win.shape[0]
+    pos = torch.empty((m, c), dtype=torch.float32, device=in_win.device)
+    _lib.call("seg3d_pos_embed", _ptr(in_win), m, _i3(window_shape), _ptr(inv_freq), int(c), _ptr(pos), _stream())
+    return pos
+
+
+# ------------------------------------------------------------------------------------------ a19-a21 attention
+class _WindowAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, tau, tau_min, heads, wi):
+        m, c = v.shape
+        dh = c // heads
+        dev = v.device
+        out = torch.empty((m, c), dtype=torch.float32, device=dev)
+        lse = torch.empty((m, heads), dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, heads), dev)
+        tau_f = tau.reshape(-1)
+        _lib.call("seg3d_window_attn_fwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
+                  _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), m, int(wi.n_windows), heads, dh,
+                  _ptr(tau_f), float(tau_min), _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+        ctx.save_for_backward(q, k, v, tau, out, lse)
+        ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, tau, out, lse = ctx.saved_tensors
+        wi, heads = ctx.wi, ctx.heads
+        m, c = v.shape
+        dev = v.device
+        dout = _f32c(dout)
+        dq, dk, dv = (torch.empty((m, c), dtype=torch.float32, device=dev) for _ in range(3))
+        dtau = torch.zeros((1,), dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, heads), dev)
+        _lib.call("seg3d_window_attn_bwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
+                  _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), m,
+                  int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), _ptr(dq), _ptr(dk),
+                  _ptr(dv), c, c, c, _ptr(dtau), _ptr(ws), ws.numel(), _stream())
+        return dq, dk, dv, dtau.reshape(tau.shape), None, None, None
+
+
+def window_attention(q, k, v, tau, tau_min, heads, wi):
+    """q, k, v: float32 [m, C] row-strided views (last dim contiguous) of the in-projection output."""
+    _need_gpu(q, k, v, tau)
+    for t in (q, k, v):
+        if t.dtype != torch.float32 or t.stride(1) != 1:
+            raise _lib.Seg3dError("q/k/v must be float32 with a contiguous last dimension")
+    return _WindowAttnFn.apply(q, k, v, tau, tau_min, heads, wi)
+
+
+# ------------------------------------------------------------------------------------------ a7/a24-a26
+class _SegmentReduceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg, mode):
+        x = _f32c(x)
+        n, c = x.shape
+        out = torch.empty((seg.n_segments, c), dtype=torch.float32, device=x.device)
+        arg = torch.empty((seg.n_segments, c), dtype=torch.int32, device=x.device) if mode == REDUCE_MAX else None
+        _lib.call("seg3d_segment_reduce_fwd", _ptr(x), c, _ptr(seg.order), _ptr(seg.offsets), seg.n_segments, mode,
+                  _ptr(out), _ptr(arg), _stream())
+        ctx.seg, ctx.mode, ctx.arg, ctx.n = seg, mode, arg, n
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        c = dout.shape[1]
+        seg = ctx.seg
+        if ctx.mode == REDUCE_MAX:
+            dx = torch.zeros((ctx.n, c), dtype=torch.float32, device=dout.device)
+        else:
+            dx = torch.empty((ctx.n, c), dtype=torch.float32, device=dout.device)
+        _lib.call("seg3d_segment_reduce_bwd", _ptr(dout), c, _ptr(seg.ids), ctx.n, _ptr(seg.offsets), _ptr(ctx.arg),
+                  seg.n_segments, ctx.mode, _ptr(dx), _stream())
+        return dx, None, None
+
+
+def segment_reduce(x, seg, mode):
+    _need_gpu(x)
+    return _SegmentReduceFn.apply(x, seg, mode)
+
+
+_MODES = {"sum": REDUCE_SUM, "add": REDUCE_SUM, "mean": REDUCE_MEAN, "max": REDUCE_MAX}
+
+
+def scatter(src, index, dim=0, reduce="sum", dim_size=None):
+    """``torch_scatter.scatter(src, index, dim=0, reduce='mean'|'max'|'sum')``: rows = index.max()+1
+    (one host sync unless ``dim_size`` is given), empty rows are 0, differentiable w.r.t. src."""
+    if dim != 0 or src.dim() != 2:
+        raise _lib.Seg3dError("scatter: only dim=0 on [N, C] tensors is on this path")
+    _need_gpu(src, index)
+    n_seg = int(index.max().item()) + 1 if dim_size is None else int(dim_size)
+    return segment_reduce(src, SegmentIndex(index, n_seg), _MODES[reduce])
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, ids, seg):
+        feats = _f32c(feats)
+        n, c = ids.shape[0], feats.shape[1]
+        out = torch.empty((n, c), dtype=torch.float32, device=feats.device)
+        _lib.call("seg3d_gather_rows", _ptr(feats), _ptr(ids), n, c, _ptr(out), _stream())
+        ctx.ids, ctx.seg, ctx.m = ids, seg, feats.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        seg = ctx.seg if ctx.seg is not None else SegmentIndex(ctx.ids, ctx.m)
+        c = dout.shape[1]
+        dfeat = torch.empty((ctx.m, c), dtype=torch.float32, device=dout.device)
+        _lib.call("seg3d_segment_reduce_fwd", _ptr(dout), c, _ptr(seg.order), _ptr(seg.offsets), ctx.m, REDUCE_SUM,
+                  _ptr(dfeat), None, _stream())
+        return dfeat, None, None
+
+
+def gather_rows(feats, ids, seg=None):
+    """out[i] = feats[ids[i]], zeros where ids[i] == -1.  ``seg`` (SegmentIndex of ids over the feature
+    rows) may be passed to reuse an existing CSR in the backward."""
+    _need_gpu(feats, ids)
+    return _GatherRowsFn.apply(feats, _i32c(ids), seg)
+
+
+def voxel_to_point(feats, coords):
+    """``seg3d.ops.voxel_to_point`` (voxel_to_point.py:4-17)."""
+    return gather_rows(feats, coords)
+
+
+def voxel_max_pooling(feats, coords):
+    """``seg3d.ops.voxel_max_pooling`` (voxel_pooling.py:62-73): rows with coords == -1 are ignored."""
+    return scatter(feats, coords, reduce="max")
+
+
+def voxel_avg_pooling(feats, coords, counts):
+    """``seg3d.ops.voxel_avg_pooling`` (voxel_pooling.py:10-60): out[M, C] with M = len(counts); rows whose
+    id is outside [0, M) are skipped (voxel_pooling.cpp:14); the divisor is the number of rows actually
+    pooled, which equals ``counts`` for every caller-side construction of it."""
+    _need_gpu(feats, coords, counts)
+    m = counts.shape[0]
+    ids = _i32c(coords)
+    ids = torch.where((ids >= 0) & (ids < m), ids, torch.full_like(ids, -1))
+    return segment_reduce(feats, SegmentIndex(ids, m), REDUCE_MEAN)

@@ -1,0 +1,254 @@
+"""Segformer / PointTransformer segmentor on the HIP path.
+
+Host-side mirror of the reference's default model (``cfg.MODEL.SEGMENTOR == 'segformer'``):
+  seg3d/models/segmentors/segformer.py:12-146, seg3d/models/backbones/pointtransformer.py:13-219,
+  seg3d/models/voxel_encoders/vfe.py, seg3d/models/layers/se_layer.py.
+Same constructor arguments, same ``forward(batch_dict) -> OrderedDict`` contract and the same
+state_dict keys / shapes (tests/golden/segformer_keys.json), so reference checkpoints load.
+
+What runs where: voxel-feature reduce, every sparse convolution, window partition + attention and
+the voxel->point gather run in libseg3d_hip.so; per-point / per-voxel dense layers (Linear, BN, LN,
+GELU) stay on torch's GEMM / elementwise kernels.  Index structures (site levels, neighbour tables,
+window CSRs, point->voxel CSR) are built once per batch and shared by all layers that use them.
+Scope: single-sweep, no image fusion (configs/waymo_one_sweep*.yaml); the multi-sweep / DeepFusion
+branch raises NotImplementedError.
+"""
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import spconv
+from .swformer import SparseWindowPartitionLayer, SWFormerBlock
+
+
+def replace_feature(out, new_features):
+    return out.replace_feature(new_features)
+
+
+def conv_module(cin, cout, norm_fn, act_fn, conv_type="subm", indice_key=None):
+    """conv (no bias) + BN + ReLU with the reference's child names '0','1','2' (spconv_utils.py:13-32)."""
+    if conv_type == "subm":
+        conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key=indice_key)
+    elif conv_type == "spconv":
+        conv = spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key=indice_key)
+    elif conv_type == "inverseconv":
+        conv = spconv.SparseInverseConv3d(cin, cout, 3, bias=False, indice_key=indice_key)
+    else:
+        raise NotImplementedError(conv_type)
+    return spconv.SparseSequential(conv, norm_fn(cout), act_fn)
+
+
+class VFE(nn.Module):
+    """Per-voxel reduce of point features (vfe.py:16-27); rows with id -1 are skipped by the CSR."""
+
+    def __init__(self, voxel_feature_channel, reduce="mean"):
+        super().__init__()
+        self.voxel_feature_channel = voxel_feature_channel
+        self.reduce = reduce
+
+    def forward(self, features, seg):
+        return ops.segment_reduce(features, seg, {"mean": ops.REDUCE_MEAN, "max": ops.REDUCE_MAX}[self.reduce])
+
+
+class FlattenSELayer(nn.Module):
+    """Squeeze-excite over each sample's rows (se_layer.py:16-29)."""
+
+    def __init__(self, channel, reduction=4):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+    def forward(self, x, indices, row_offsets=None):
+        """``row_offsets`` (python ints, cumulative rows per sample) lets the mean run on contiguous slices --
+        samples are contiguous after collate_batch -- instead of a scatter over <= batch_size huge segments."""
+        indices = indices.long()
+        if row_offsets is not None:
+            starts = [0] + list(row_offsets[:-1])
+            pooled = torch.stack([x[s:e].mean(dim=0) if e > s else x.new_zeros(x.shape[1])
+                                  for s, e in zip(starts, row_offsets)])
+        else:
+            pooled = ops.scatter(x, indices, reduce="mean")
+        return x * self.fc(pooled)[indices]
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    def __init__(self, inplanes, planes, norm_fn, act_fn, indice_key=None):
+        super().__init__()
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, 3, padding=1, bias=True, indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.act = act_fn
+        self.conv2 = spconv.SubMConv3d(planes, planes, 3, padding=1, bias=True, indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+
+    def forward(self, x):
+        y = self.conv1(x)
+        y = y.replace_feature(self.act(self.bn1(y.features)))
+        y = self.conv2(y)
+        return y.replace_feature(self.act(self.bn2(y.features) + x.features))
+
+
+class UpBlock(spconv.SparseModule):
+    def __init__(self, inplanes, planes, norm_fn, act_fn, conv_type, layer_id):
+        super().__init__()
+        self.transform = SparseBasicBlock(inplanes, inplanes, norm_fn, act_fn, indice_key=f"subm{layer_id}")
+        self.bottleneck = conv_module(2 * inplanes, inplanes, norm_fn, act_fn, "subm", f"subm{layer_id}")
+        key = f"spconv{layer_id}" if conv_type == "inverseconv" else f"subm{layer_id}"
+        self.out = conv_module(inplanes, planes, norm_fn, act_fn, conv_type, key)
+
+    def forward(self, x_bottom, x_lateral):
+        t = self.transform(x_lateral)
+        cat = torch.cat([x_bottom.features, t.features], dim=1)
+        m = self.bottleneck(t.replace_feature(cat)).features
+        # channel_reduction (pointtransformer.py:88-102): sum adjacent channel pairs of the concat
+        skip = cat.view(cat.shape[0], m.shape[1], -1).sum(dim=2)
+        return self.out(t.replace_feature(m + skip))
+
+
+class PointTransformer(nn.Module):
+    def __init__(self, input_channels, output_channels, grid_size, voxel_size, point_cloud_range, batching_info,
+                 window_shape, drop_path_rate, depths, num_classes):
+        super().__init__()
+        self.sparse_shape = [int(g) for g in grid_size][::-1]  # (z, y, x)
+        self.voxel_size, self.point_cloud_range = voxel_size, point_cloud_range
+        self.depths = list(depths)
+        grid_xyz = [float(g) for g in grid_size]
+        self.norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.act_fn = nn.ReLU(inplace=True)
+        norm_fn, act_fn = self.norm_fn, self.act_fn
+
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 48, 3, padding=1, bias=False, indice_key="subm1"), norm_fn(48), act_fn)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(self.depths))]
+        widths = (48, 96, 192, 384)
+        for k, c in enumerate(widths):
+            lo, hi = sum(self.depths[:k]), sum(self.depths[:k + 1])
+            stage = nn.Sequential(
+                SparseWindowPartitionLayer(batching_info[k], window_shape, [g / (2 ** k) for g in grid_xyz]),
+                SWFormerBlock(c, 8, depth=self.depths[k], drop_path=dpr[lo:hi]))
+            setattr(self, f"swformer_block{k + 1}", stage)
+        for k in (1, 2, 3):
+            setattr(self, f"conv_down{k}", conv_module(widths[k - 1], widths[k], norm_fn, act_fn, "spconv",
+                                                       f"spconv{k + 1}"))
+        self.up4 = UpBlock(384, 192, norm_fn, act_fn, "inverseconv", 4)
+        self.up3 = UpBlock(192, 96, norm_fn, act_fn, "inverseconv", 3)
+        self.up2 = UpBlock(96, 48, norm_fn, act_fn, "inverseconv", 2)
+        self.up1 = UpBlock(48, output_channels, norm_fn, act_fn, "subm", 1)
+        self.aux_voxel_classifier = nn.Sequential(nn.Linear(384, num_classes, bias=False))
+        self.voxel_classifier = nn.Sequential(nn.Linear(output_channels, num_classes, bias=False))
+
+    def forward(self, batch_dict):
+        x = spconv.SparseConvTensor(features=batch_dict["voxel_features"], indices=batch_dict["voxel_coords"].int(),
+                                    spatial_shape=self.sparse_shape, batch_size=batch_dict["batch_size"])
+        x1 = self.conv_input(x)
+        x1 = x1.replace_feature(self.swformer_block1(x1))
+        x2 = self.conv_down1(x1)
+        x2 = x2.replace_feature(self.swformer_block2(x2))
+        x3 = self.conv_down2(x2)
+        x3 = x3.replace_feature(self.swformer_block3(x3))
+        x4 = self.conv_down3(x3)
+        x4 = x4.replace_feature(self.swformer_block4(x4))
+
+        batch_dict["aux_voxel_out"] = self.aux_voxel_classifier(x4.features)
+        batch_dict["aux_voxel_coords"] = x4.indices
+
+        y = self.up4(x4, x4)
+        y = self.up3(y, x3)
+        y = self.up2(y, x2)
+        y = self.up1(y, x1)
+        batch_dict["voxel_features"] = y.features
+        batch_dict["voxel_coords"] = y.indices
+        batch_dict["voxel_out"] = self.voxel_classifier(y.features)
+        return batch_dict
+
+
+def _bn_mlp(dims, first_bn=None, last_plain=False):
+    """[BN(d0)] + (Linear(no bias) + BN + ReLU)* [+ Linear(bias)] with the reference's Sequential numbering."""
+    mods = [nn.BatchNorm1d(first_bn)] if first_bn is not None else []
+    n = len(dims) - 1
+    for i in range(n):
+        if last_plain and i == n - 1:
+            mods.append(nn.Linear(dims[i], dims[i + 1]))
+        else:
+            mods += [nn.Linear(dims[i], dims[i + 1], bias=False), nn.BatchNorm1d(dims[i + 1]), nn.ReLU(inplace=True)]
+    return nn.Sequential(*mods)
+
+
+class Segformer(nn.Module):
+    def __init__(self, dataset, batching_info, window_shape, depths, drop_path_rate):
+        super().__init__()
+        dim_point = dataset.dim_point + (2 if dataset.use_cylinder else 0)
+        if dataset.use_multi_sweeps or dataset.use_image_feature:
+            raise NotImplementedError("multi-sweep / image-fusion inputs are the next scope row (SURVEY.md 8f)")
+        self.use_multi_sweeps = False
+        self.use_image_feature = False
+        self.point_feature_channel = 64
+        self.point_encoder = _bn_mlp([dim_point, 64, 128, 256, self.point_feature_channel], first_bn=dim_point,
+                                     last_plain=True)
+        self.vfe = VFE(self.point_feature_channel, reduce="max")
+        self.scatter = VFE(3, reduce="mean")  # present (and unused) in the reference: segformer.py:39
+        self.voxel_feature_channel = 32
+        self.point_transformer = PointTransformer(
+            self.vfe.voxel_feature_channel, self.voxel_feature_channel, dataset.grid_size, dataset.voxel_size,
+            dataset.point_cloud_range, batching_info=batching_info, window_shape=window_shape, depths=depths,
+            drop_path_rate=drop_path_rate, num_classes=dataset.num_classes)
+        self.fusion_feature_channel = 64
+        self.fusion_encoder = _bn_mlp([self.point_feature_channel + self.voxel_feature_channel, 256, 128,
+                                       self.fusion_feature_channel])
+        self.se = FlattenSELayer(self.fusion_feature_channel)
+        self.classifier = nn.Sequential(nn.Linear(self.fusion_feature_channel, 64, bias=False), nn.BatchNorm1d(64),
+                                        nn.ReLU(True), nn.Dropout(0.3),
+                                        nn.Linear(64, dataset.num_classes, bias=False))
+        self.weight_initialization()
+
+    def weight_initialization(self):
+        """segformer.py:78-92: kaiming-normal Linear weights, unit norms; sparse convs keep their default init."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, (nn.BatchNorm1d, nn.LayerNorm)):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, batch_dict):
+        points = batch_dict["points"][:, 1:]
+        ids = batch_dict["point_voxel_ids"]
+        n_voxels = batch_dict["voxel_coords"].shape[0]
+        point_features = self.point_encoder(points)
+
+        # point <-> voxel CSR: built once, used by the VFE reduce and by the gather's backward
+        seg = batch_dict.get("point_voxel_index")
+        if seg is None:
+            seg = ops.SegmentIndex(ids, n_voxels)
+        batch_dict["voxel_features"] = self.vfe(point_features, seg)
+        batch_dict = self.point_transformer(batch_dict)
+
+        point_voxel_features = ops.gather_rows(batch_dict["voxel_features"], seg.ids, seg)
+        fused = self.fusion_encoder(torch.cat([point_features, point_voxel_features], dim=1))
+
+        # cumulative rows per sample: python ints from the batch builder, else the collated float tensor
+        row_offsets = batch_dict.get("point_row_offsets")
+        if row_offsets is None and batch_dict.get("point_id_offset") is not None:
+            row_offsets = [int(v) for v in batch_dict["point_id_offset"].tolist()]
+        fused = fused + self.se(fused, batch_dict["points"][:, 0], row_offsets)
+
+        result = OrderedDict()
+        result["point_out"] = self.classifier(fused)
+        result["voxel_out"] = batch_dict["voxel_out"]
+        result["aux_voxel_out"] = batch_dict["aux_voxel_out"]
+        result["voxel_coords"] = batch_dict["voxel_coords"]
+        result["aux_voxel_coords"] = batch_dict["aux_voxel_coords"]
+        return result
+
+
+def build_segmentor(cfg, dataset):
+    """seg3d/models/builder.py:8-23 for the segformer branch."""
+    if cfg.MODEL.SEGMENTOR != "segformer":
+        raise NotImplementedError("only MODEL.SEGMENTOR='segformer' (the default every shipped config uses)")
+    batching_info = [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO]
+    return Segformer(dataset=dataset, batching_info=batching_info, window_shape=cfg.MODEL.WINDOW_SHAPE,
+                     depths=cfg.MODEL.DEPTHS, drop_path_rate=cfg.MODEL.DROP_PATH_RATE)

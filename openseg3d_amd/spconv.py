@@ -1,0 +1,169 @@
+"""``spconv.pytorch``-shaped sparse-convolution modules on the HIP rulebook / gather-GEMM kernels.
+
+Only the surface the reference touches is provided (call sites
+seg3d/utils/spconv_utils.py:13-32, seg3d/models/backbones/pointtransformer.py:13-113,184-189):
+``SparseConvTensor``, ``SubMConv3d``, ``SparseConv3d``, ``SparseInverseConv3d``,
+``SparseSequential``, ``SparseModule``.  ``openseg3d_amd.compat.install()`` registers this module
+as ``spconv.pytorch`` so the reference's model files import it unchanged.
+
+Design differences from spconv (MI355X-first):
+  * a resolution level (``SiteLevel``) owns its coordinate hash and its neighbour tables; tables
+    are pure functions of the active-site set, so ``indice_key`` only decides *which level* an
+    inverse convolution returns to -- the cache the key names in spconv falls out of the level
+    object being shared by every tensor that lives on it;
+  * tables are output-stationary ([27][rows], -1 = inactive): forward, dgrad and wgrad all read the
+    same two tables, nothing is scattered with atomics;
+  * strided-conv output sites come out in ascending (b, z, y, x) order (build-defined; per-point
+    logits do not depend on it).
+Parameters: ``weight`` [Cout, 3, 3, 3, Cin] (+ ``bias`` [Cout]); default init = kaiming-uniform
+(a=sqrt(5)) over fan_in = 27*Cin, bias uniform(+-1/sqrt(fan_in)), as torch's conv layers do.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class SiteLevel:
+    """Active sites of one resolution level and everything derived from them (built lazily, once)."""
+
+    def __init__(self, coords, spatial_shape, batch_size):
+        self.coords = coords if coords.dtype == torch.int32 else coords.to(torch.int32)
+        self.coords = self.coords.contiguous()
+        self.shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self._hash = None
+        self._subm = None
+        self._down = None
+
+    @property
+    def hash(self):
+        if self._hash is None:
+            self._hash = ops.CoordHash(self.coords, self.shape)
+        return self._hash
+
+    def subm(self):
+        """[27, M] table of SubMConv3d(k=3, padding=1)."""
+        if self._subm is None:
+            self._subm = ops.rulebook_subm(self.hash)
+        return self._subm
+
+    def down(self):
+        """(coarse SiteLevel, nbr_fwd [27, M_coarse], nbr_inv [27, M]) of SparseConv3d(k=3, s=2, p=1)."""
+        if self._down is None:
+            co, shape_out = ops.downsample_coords(self.coords, self.batch_size, self.shape)
+            fwd, inv = ops.rulebook_strided(self.hash, co)
+            self._down = (SiteLevel(co, shape_out, self.batch_size), fwd, inv)
+        return self._down
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, _level=None, _indice_dict=None):
+        self.features = features
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.level = _level if _level is not None else SiteLevel(indices, self.spatial_shape, batch_size)
+        self.indices = self.level.coords
+        self.indice_dict = _indice_dict if _indice_dict is not None else {}
+
+    def replace_feature(self, new_features):
+        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.level,
+                                self.indice_dict)
+
+    def on_level(self, features, level):
+        return SparseConvTensor(features, level.coords, level.shape, self.batch_size, level, self.indice_dict)
+
+
+class SparseModule(nn.Module):
+    """Marker base class: SparseSequential hands these the SparseConvTensor itself."""
+
+
+class _Conv3x3x3(SparseModule):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, bias=True,
+                 indice_key=None):
+        super().__init__()
+        ks = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        if ks != 3 or dilation != 1:
+            raise NotImplementedError("only 3x3x3, dilation 1 is on the OpenSeg3D path")
+        if in_channels % 16 or out_channels % 16:
+            raise NotImplementedError("channel counts must be multiples of 16 (MFMA 16x16x4 tiles)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.stride, self.padding, self.indice_key = stride, padding, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, 3, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._packed = None  # (weight version, packed tensor) for no-grad forwards
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        fan_in = 27 * self.in_channels
+        nn.init.kaiming_uniform_(self.weight.view(self.out_channels, -1), a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _packed_weight(self):
+        """Forward-operand pack, cached while the weight is unchanged (weights are static in eval)."""
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        if self._packed is None or self._packed[0] != key:
+            with torch.no_grad():
+                self._packed = (key, ops.pack_weight(w, ops.PACK_FWD))
+        return self._packed[1]
+
+    def _apply_tables(self, feats, nbr, nbr_t, t_flags):
+        return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight())
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size=3, stride={self.stride}, " \
+               f"padding={self.padding}, indice_key={self.indice_key!r}"
+
+
+class SubMConv3d(_Conv3x3x3):
+    def forward(self, x):
+        nbr = x.level.subm()
+        return x.replace_feature(self._apply_tables(x.features, nbr, nbr, ops.PACK_T_FLIP))
+
+
+class SparseConv3d(_Conv3x3x3):
+    def forward(self, x):
+        if self.stride != 2 or self.padding != 1:
+            raise NotImplementedError("only SparseConv3d(k=3, stride=2, padding=1) is on the OpenSeg3D path")
+        coarse, fwd, inv = x.level.down()
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = x.level
+        return x.on_level(self._apply_tables(x.features, fwd, inv, ops.PACK_T), coarse)
+
+
+class SparseInverseConv3d(_Conv3x3x3):
+    def __init__(self, in_channels, out_channels, kernel_size=3, bias=True, indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, bias=bias, indice_key=indice_key)
+
+    def forward(self, x):
+        fine = x.indice_dict.get(self.indice_key)
+        if fine is None:
+            raise KeyError(f"SparseInverseConv3d: no strided conv registered indice_key={self.indice_key!r}")
+        coarse, fwd, inv = fine.down()
+        if coarse is not x.level:
+            raise RuntimeError("SparseInverseConv3d input does not live on the paired strided conv's output sites")
+        return x.on_level(self._apply_tables(x.features, inv, fwd, ops.PACK_T), fine)
+
+
+class SparseSequential(SparseModule):
+    """Runs SparseModules on the sparse tensor and plain nn.Modules (BN, ReLU, ...) on ``.features``."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            if isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                x = x.replace_feature(m(x.features))
+            else:
+                x = m(x)
+        return x

@@ -1,0 +1,197 @@
+"""Sparse-window transformer stage (SWFormer) on the HIP window-partition / attention kernels.
+
+Mirrors the module tree -- hence the state_dict keys -- of
+seg3d/models/layers/point_transformer_layer.py (SparseWindowPartitionLayer, WindowAttention, MLP,
+EncoderLayer, SWFormerBlock) and seg3d/models/layers/cosine_msa.py (CosineMultiheadAttention):
+``layers.{i}.win_attn.self_attn.{in_proj_weight,in_proj_bias,out_proj.weight,out_proj.bias,tau}``,
+``layers.{i}.norm{1,2}``, ``layers.{i}.mlp.fc{1,2}``.
+
+What changed underneath (MI355X-first):
+  * windows stay ragged: the partition emits a CSR of non-empty windows and the attention kernel
+    consumes it directly; the reference's padded [W, T, C] tensors, their -inf masks and the
+    flat2window / window2flat copies in every encoder layer (swformer_utils.py:34-85) do not exist;
+  * one device pass per (stage, shift) builds every index with no host sync; the counts the host
+    needs (windows per shift) are fetched once per stage;
+  * activation checkpointing (point_transformer_layer.py:321-337) is not used: 288 GB of HBM holds
+    the activations of a 180 k-point scene many times over.
+Dense projections / MLP / LayerNorm stay on torch (rocBLAS/hipBLASLt GEMMs).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def window_geometry(sparse_shape_xyz, window_shape, do_shift):
+    """Host-side constants of get_window_coors (swformer_utils.py:108-131): windows per axis and shift."""
+    win = [int(w) for w in window_shape]
+    if len(win) != 3:
+        raise NotImplementedError("3-D windows only (config.py:68 WINDOW_SHAPE)")
+    s = [float(v) for v in sparse_shape_xyz]
+    nwin = [int(np.ceil(s[i] / win[i]) + 1) for i in range(3)]
+    shift = [w // 2 for w in win] if do_shift else list(win)
+    if s[2] == win[2]:
+        shift[2] = 0
+    return win, nwin, shift
+
+
+class WindowPlan:
+    """Everything one SWFormer stage needs about the active sites: per shift a WindowIndex (CSR of
+    windows) and the positional embedding in flat voxel order."""
+
+    def __init__(self, index, pos):
+        self.index = index  # [shift] -> ops.WindowIndex
+        self.pos = pos      # [shift] -> float32 [M, C]
+
+
+class SparseWindowPartitionLayer(nn.Module):
+    """Window grouping + positional embedding (no parameters).  Called with a sparse tensor it returns a
+    ``voxel_info`` dict shaped like the reference's (features + plan) for SWFormerBlock."""
+
+    def __init__(self, batching_info, window_shape, sparse_shape, normalize_pos=False, pos_temperature=1000):
+        super().__init__()
+        if normalize_pos:
+            raise NotImplementedError("normalize_pos=True is never enabled on the reference path")
+        self.batching_info = batching_info
+        self.window_shape = [int(w) for w in window_shape]
+        self.sparse_shape = [float(s) for s in sparse_shape]  # (x, y, z), may be fractional
+        self.pos_temperature = pos_temperature
+        self._inv_freq = {}
+
+    def levels(self):
+        return [(v["batching_range"][0], v["batching_range"][1], v["max_tokens"])
+                for _, v in sorted(self.batching_info.items())]
+
+    def inv_freq(self, feat_dim, device):
+        """pos_temperature ** (2 * (j // 2) / pos_length), evaluated by torch exactly as at
+        point_transformer_layer.py:180-184 so the divisor is bit-identical."""
+        key = (feat_dim, str(device))
+        if key not in self._inv_freq:
+            plen = feat_dim // 3
+            t = torch.arange(plen, dtype=torch.float32)
+            t = self.pos_temperature ** (2 * torch.div(t, 2, rounding_mode="floor") / plen)
+            self._inv_freq[key] = t.to(device)
+        return self._inv_freq[key]
+
+    @torch.no_grad()
+    def plan(self, coords, batch_size, feat_dim, want_debug=False):
+        if feat_dim % 3 or (feat_dim // 3) % 2:
+            raise ValueError("feature dim must be divisible by 6 (point_transformer_layer.py:176,196)")
+        index, pos = [], []
+        for s in range(2):
+            win, nwin, shift = window_geometry(self.sparse_shape, self.window_shape, s == 1)
+            wi = ops.window_partition(coords, batch_size, win, nwin, shift, self.levels(), want_debug=want_debug)
+            index.append(wi)
+            pos.append(ops.pos_embed(wi.in_win, win, self.inv_freq(feat_dim, coords.device), feat_dim))
+        counts = torch.stack([wi.counts for wi in index]).tolist()  # the stage's one host sync
+        for wi, (n_win, n_drop) in zip(index, counts):
+            wi.n_windows, wi.n_dropped = int(n_win), int(n_drop)
+            if n_drop:
+                raise RuntimeError(
+                    f"{n_drop} voxels exceed max_tokens of their batching level: voxel dropping is "
+                    "unsupported (it breaks replace_feature in the reference too, SURVEY.md 8 quirk 1)")
+        return WindowPlan(index, pos)
+
+    def forward(self, x):
+        feats = x.features
+        return {"voxel_features": feats, "plan": self.plan(x.indices, x.batch_size, feats.shape[1])}
+
+
+class CosineMultiheadAttention(nn.Module):
+    """Parameters of cosine_msa.CosineMultiheadAttention (packed in-proj, out-proj, shared tau); the
+    attention core runs in seg3d_window_attn_fwd/bwd."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, tau_min=0.01):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.tau_min, self.dropout = embed_dim, num_heads, tau_min, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.tau = nn.Parameter(torch.ones(1, 1, 1))
+        nn.init.xavier_uniform_(self.in_proj_weight)  # nn.MultiheadAttention._reset_parameters
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def forward(self, x, pos, wi):
+        """x [M, C] flat voxel features, pos [M, C]; q = k = (x + pos) W_qk, v = x W_v (cosine_msa.py:58-63)."""
+        c = self.embed_dim
+        qk = F.linear(x + pos, self.in_proj_weight[: 2 * c], self.in_proj_bias[: 2 * c])
+        v = F.linear(x, self.in_proj_weight[2 * c:], self.in_proj_bias[2 * c:])
+        o = ops.window_attention(qk[:, :c], qk[:, c:], v, self.tau, self.tau_min, self.num_heads, wi)
+        return self.out_proj(o)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, d_model, nhead, attn_drop, tau_min=0.01):
+        super().__init__()
+        self.self_attn = CosineMultiheadAttention(d_model, nhead, dropout=attn_drop, tau_min=tau_min)
+
+    def forward(self, feat_2d, pos, wi):
+        return self.self_attn(feat_2d, pos, wi)
+
+
+class MLP(nn.Module):
+    def __init__(self, in_features, hidden_features, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+        self.drop = drop
+
+    def forward(self, x):
+        x = F.gelu(self.fc1(x))
+        if self.drop and self.training:
+            x = F.dropout(x, self.drop)
+        x = self.fc2(x)
+        if self.drop and self.training:
+            x = F.dropout(x, self.drop)
+        return x
+
+
+def drop_path(x, p, training):
+    """Per-row stochastic depth (seg3d/models/layers/drop.py:6-19)."""
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+    if keep > 0.0:
+        mask.div_(keep)
+    return x * mask
+
+
+class EncoderLayer(nn.Module):
+    """Post-norm encoder layer: x + DP(LN1(attn(x))), then + DP(LN2(mlp(.))) (point_transformer_layer.py:289-298)."""
+
+    def __init__(self, d_model, nhead, mlp_hidden_dim, drop=0.0, attn_drop=0.1, drop_path_rate=0.0):
+        super().__init__()
+        self.win_attn = WindowAttention(d_model, nhead, attn_drop)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.mlp = MLP(d_model, mlp_hidden_dim, drop=drop)
+        self.drop_path_rate = float(drop_path_rate)
+
+    def forward(self, x, pos, wi):
+        x = x + drop_path(self.norm1(self.win_attn(x, pos, wi)), self.drop_path_rate, self.training)
+        return x + drop_path(self.norm2(self.mlp(x)), self.drop_path_rate, self.training)
+
+
+class SWFormerBlock(nn.Module):
+    def __init__(self, d_model, nhead, depth=4, mlp_ratio=2.0, attn_drop=0.1, drop=0.0, drop_path=0.0):
+        super().__init__()
+        self.depth = depth
+        rates = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * depth
+        self.layers = nn.ModuleList(
+            EncoderLayer(d_model, nhead, int(d_model * mlp_ratio), drop=drop, attn_drop=attn_drop,
+                         drop_path_rate=rates[i]) for i in range(depth))
+
+    def forward(self, voxel_info):
+        x, plan = voxel_info["voxel_features"], voxel_info["plan"]
+        half = int(self.depth / 2)  # first depth//2 layers on the unshifted windows (:321-337)
+        for i, layer in enumerate(self.layers):
+            s = 0 if i < half else 1
+            x = layer(x, plan.pos[s], plan.index[s])
+        return x

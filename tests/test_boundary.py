@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, the product package never reaches into oracle/, and the ops refuse to run without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from openseg3d_amd import _lib
+    declared = _lib.header_symbols()
+    assert len(declared) >= 25
+    assert sorted(_lib.SIGNATURES) == declared, "binding table and include/seg3d_hip.h disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in seg3d_hip.h but not exported"
+    assert _lib.load().seg3d_abi_version() == _lib.ABI_VERSION
+
+
+def test_header_cites_reference_interfaces():
+    text = open(os.path.join(ROOT, "include", "seg3d_hip.h")).read()
+    for cite in ("voxel_generator.py:55-153", "ingroup_inds_cuda.cu:12-25", "spconv_utils.py:13-32",
+                 "swformer_utils.py", "cosine_msa.py:115-177", "voxel_pooling_cuda.cu:10-79", "voxel_to_point.py:4-17"):
+        assert cite in text, cite
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "openseg3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            uses = re.findall(r"^\s*(?:from|import)\s+oracle\b.*$", src, flags=re.M)
+            if f == "selfcheck.py":  # smoke()'s checker, allowed by the rules
+                continue
+            assert not uses, f"{f} imports the oracle: {uses}"
+            assert "/root/reference" not in src, f"{f} reads the reference tree at run time"
+
+
+def test_ops_fail_loudly_without_gpu():
+    from openseg3d_amd import _lib, ops
+    x = torch.zeros(4, 6)
+    with pytest.raises(_lib.Seg3dError):
+        ops.voxelize(x, [0.1, 0.1, 0.1], [-72, -72, -2, 72, 72, 4.4])
+    with pytest.raises(_lib.Seg3dError):
+        ops.voxel_to_point(torch.zeros(3, 4), torch.zeros(5, dtype=torch.long))
+    with pytest.raises(_lib.Seg3dError):
+        ops.get_inner_win_inds(torch.zeros(5, dtype=torch.long))
+
+
+def test_host_only_entry_points():
+    from openseg3d_amd import _lib, ops
+    assert ops.grid_size([0.1, 0.1, 0.1], [-72, -72, -2, 72, 72, 4.4]) == [1440, 1440, 64]
+    assert ops.grid_size([0.05, 0.012, 0.1], [0, -3.1415926, -2, 75.2, 3.1415926, 5.2]) == [1504, 524, 72]
+    assert _lib.query("seg3d_voxelize_workspace_bytes", 180000) > 180000 * 12
+    assert _lib.query("seg3d_coord_hash_bytes", 1000) == 2048 * 12
+    # argument validation happens before anything is enqueued: a null call is rejected, not launched
+    assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, None, 48, 48, None, None) == _lib.EINVAL
+    assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, None, 50, 48, None, None) == _lib.EINVAL

@@ -1,0 +1,408 @@
+"""GPU parity tests: the HIP path (through the C ABI in libseg3d_hip.so) against the CPU oracle and the
+golden fixtures generated from the reference's own Python.  Integer / index work is bit-exact;
+floating-point tolerances are written next to each comparison."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import refcfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from openseg3d_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------ a1, a2, a4
+@pytest.mark.parametrize("tag,rng,vs", [("cart", refcfg.CART_RANGE, refcfg.CART_VOXEL),
+                                        ("cyl", refcfg.CYL_RANGE, refcfg.CYL_VOXEL)])
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_voxelize_bit_exact_vs_reference(dev, golden_dir, tag, rng, vs, dt):
+    from openseg3d_amd import ops
+    d = np.load(os.path.join(golden_dir, "voxelize.npz"))
+    k = f"{tag}_{dt}"
+    pts = torch.from_numpy(d[k + "_points"]).to(dev)
+    coords, ids = ops.voxelize(pts, vs, rng)
+    assert np.array_equal(_np(coords)[:, 1:], d[k + "_coors"])
+    assert (_np(coords)[:, 0] == 0).all()
+    assert np.array_equal(_np(ids), d[k + "_ids"])
+    assert ops.grid_size(vs, rng) == d[tag + "_grid"].tolist()
+
+
+def test_voxelize_batched_matches_per_sample_collate(dev):
+    from oracle import index_ops
+    from openseg3d_amd import batch, scene
+    samples = [scene.make_scene(0)[:60000], scene.make_small_scene(5, 3000), np.zeros((0, 6), np.float32),
+               scene.make_scene(1)[:20000]]
+    b = batch.make_batch(samples, refcfg.CART_VOXEL, refcfg.CART_RANGE)
+    coords, ids, count = [], [], 0
+    for i, s in enumerate(samples):
+        c, p = index_ops.voxelize(s, refcfg.CART_VOXEL, refcfg.CART_RANGE)
+        p = p.copy()
+        p[p != -1] += count  # waymo_dataset.py:356-360
+        count += c.shape[0]
+        coords.append(np.pad(c, ((0, 0), (1, 0)), constant_values=i))
+        ids.append(p)
+    assert np.array_equal(_np(b["voxel_coords"]).astype(np.int32), np.concatenate(coords))
+    assert np.array_equal(_np(b["point_voxel_ids"]), np.concatenate(ids))
+    assert b["voxel_coords"].dtype == torch.float32 and b["point_voxel_ids"].dtype == torch.int64
+
+
+def test_voxelize_empty_and_all_rejected(dev):
+    from openseg3d_amd import ops
+    c, i = ops.voxelize(torch.zeros((0, 6), device=dev), refcfg.CART_VOXEL, refcfg.CART_RANGE)
+    assert c.shape == (0, 4) and i.shape == (0,)
+    c, i = ops.voxelize(torch.full((100, 6), 1e6, device=dev), refcfg.CART_VOXEL, refcfg.CART_RANGE)
+    assert c.shape == (0, 4) and (_np(i) == -1).all()
+
+
+# ------------------------------------------------------------------------------------------ a14
+def test_group_index_is_stable_rank(dev):
+    from oracle import index_ops
+    from openseg3d_amd import ops
+    rs = np.random.RandomState(0)
+    g = rs.randint(0, 500, 20000).astype(np.int64)
+    g[rs.rand(20000) < 0.3] = 7  # one large group (6k elements)
+    r = ops.get_inner_win_inds(torch.from_numpy(g).to(dev))
+    assert r.dtype == torch.int64
+    assert np.array_equal(_np(r), index_ops.ingroup_rank(g))
+    g32 = g.astype(np.int32)
+    g32[::11] = -1
+    rank, order, offs = ops.group_index(torch.from_numpy(g32).to(dev), 500)
+    order, offs, rank = _np(order), _np(offs), _np(rank)
+    assert offs[0] == 0 and offs[-1] == (g32 >= 0).sum()
+    for grp in (0, 7, 499):
+        rows = order[offs[grp]:offs[grp + 1]]
+        assert np.array_equal(rows, np.nonzero(g32 == grp)[0])
+    assert (rank[g32 < 0] == -1).all()
+
+
+# ------------------------------------------------------------------------------------------ a8-a11 rulebooks
+def _golden_coords(golden_dir, tag="cart"):
+    d = np.load(os.path.join(golden_dir, f"segformer_{tag}.npz"))
+    return d["voxel_coords"].astype(np.int32), int(d["batch_size"])
+
+
+@pytest.mark.parametrize("tag,grid", [("cart", refcfg.GRID_CART), ("cyl", refcfg.GRID_CYL)])
+def test_rulebooks_bit_exact_all_levels(dev, golden_dir, tag, grid):
+    from oracle import sparse_conv as sc
+    from openseg3d_amd import spconv
+    coords, bs = _golden_coords(golden_dir, tag)
+    shape = grid[::-1].tolist()
+    ref = sc.Sites(coords, shape)
+    lvl = spconv.SiteLevel(torch.from_numpy(coords).to(dev), shape, bs)
+    for _ in range(4):
+        assert np.array_equal(_np(lvl.subm()), ref.subm())
+        rc, rf, ri = ref.down()
+        c, f, i = lvl.down()
+        assert c.shape == rc.shape.tolist()
+        assert np.array_equal(_np(c.coords), rc.coords)
+        assert np.array_equal(_np(f), rf)
+        assert np.array_equal(_np(i), ri)
+        lvl, ref = c, rc
+
+
+def test_rulebook_dense_scene_and_edges(dev):
+    """Full-occupancy block touching the grid border: every offset and the out-of-range guards are exercised."""
+    from oracle import sparse_conv as sc
+    from openseg3d_amd import spconv
+    z, y, x = np.meshgrid(np.arange(5), np.arange(7), np.arange(6), indexing="ij")
+    block = np.stack([np.zeros(z.size), z.ravel(), y.ravel(), x.ravel()], 1).astype(np.int32)
+    far = block.copy()
+    far[:, 0] = 1
+    far[:, 1:] += np.array([3, 4, 2])
+    coords = np.concatenate([block, far])
+    coords = coords[np.random.RandomState(0).permutation(coords.shape[0])]
+    shape = [8, 11, 8]
+    ref, lvl = sc.Sites(coords, shape), spconv.SiteLevel(torch.from_numpy(coords).to(dev), shape, 2)
+    assert np.array_equal(_np(lvl.subm()), ref.subm())
+    rc, rf, ri = ref.down()
+    c, f, i = lvl.down()
+    assert np.array_equal(_np(c.coords), rc.coords) and np.array_equal(_np(f), rf) and np.array_equal(_np(i), ri)
+
+
+# ------------------------------------------------------------------------------------------ a9-a11 conv math
+@pytest.mark.parametrize("cin,cout", [(64, 48), (48, 32), (96, 48), (192, 96), (768, 384)])
+def test_sparse_conv_forward_and_backward(dev, golden_dir, cin, cout):
+    from oracle import sparse_conv as sc
+    from openseg3d_amd import spconv
+    coords, bs = _golden_coords(golden_dir)
+    if cin >= 192:
+        coords = coords[:700]
+    shape = refcfg.GRID_CART[::-1].tolist()
+    ref = sc.Sites(coords, shape)
+    m = coords.shape[0]
+    torch.manual_seed(cin + cout)
+    x = torch.randn(m, cin, dtype=torch.float64)
+    w = torch.randn(cout, 3, 3, 3, cin, dtype=torch.float64) / (27 * cin) ** 0.5
+    b = torch.randn(cout, dtype=torch.float64)
+
+    def run_ref(kind):
+        xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        if kind == "subm":
+            y = sc.subm_conv(xr, ref, wr, br)
+        elif kind == "down":
+            y, _ = sc.strided_conv(xr, ref, wr, br)
+        g = torch.randn(y.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+        y.backward(g)
+        return y.detach(), g, xr.grad, wr.grad, br.grad
+
+    for kind, cls in (("subm", spconv.SubMConv3d), ("down", spconv.SparseConv3d)):
+        y_ref, g, dx_ref, dw_ref, db_ref = run_ref(kind)
+        kw = dict(padding=1) if kind == "subm" else dict(stride=2, padding=1, indice_key="k")
+        conv = cls(cin, cout, 3, bias=True, **kw).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(w.float())
+            conv.bias.copy_(b.float())
+        xt = spconv.SparseConvTensor(x.float().to(dev).requires_grad_(), torch.from_numpy(coords).to(dev), shape, bs)
+        out = conv(xt)
+        # fp32 MFMA chain vs fp64 reference: |err| <~ 1e-6 * sum|a*b|; values are O(1)
+        assert float((out.features.detach().cpu().double() - y_ref).abs().max()) < 2e-5
+        out.features.backward(g.float().to(dev))
+        assert float((xt.features.grad.cpu().double() - dx_ref).abs().max()) < 2e-5
+        assert float((conv.bias.grad.cpu().double() - db_ref).abs().max()) < 1e-3 * max(1.0, float(db_ref.abs().max()))
+        scale = max(1.0, float(dw_ref.abs().max()))
+        assert float((conv.weight.grad.cpu().double() - dw_ref).abs().max()) < 1e-4 * scale
+
+
+def test_inverse_conv_forward_and_backward(dev, golden_dir):
+    from oracle import sparse_conv as sc
+    from openseg3d_amd import spconv
+    coords, bs = _golden_coords(golden_dir)
+    shape = refcfg.GRID_CART[::-1].tolist()
+    ref = sc.Sites(coords, shape)
+    coarse, _, _ = ref.down()
+    cin, cout = 96, 48
+    torch.manual_seed(3)
+    xc = torch.randn(coarse.coords.shape[0], cin, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, 3, 3, 3, cin, dtype=torch.float64) / (27 * cin) ** 0.5).requires_grad_()
+    y_ref = sc.inverse_conv(xc, ref, w)
+    g = torch.randn(y_ref.shape, dtype=torch.float64)
+    y_ref.backward(g)
+
+    down = spconv.SparseConv3d(16, cin, 3, stride=2, padding=1, bias=False, indice_key="spconv2").to(dev)
+    inv = spconv.SparseInverseConv3d(cin, cout, 3, bias=False, indice_key="spconv2").to(dev)
+    with torch.no_grad():
+        inv.weight.copy_(w.detach().float())
+    fine = spconv.SparseConvTensor(torch.zeros(coords.shape[0], 16, device=dev), torch.from_numpy(coords).to(dev),
+                                   shape, bs)
+    mid = down(fine)
+    xin = xc.detach().float().to(dev).requires_grad_()
+    out = inv(mid.replace_feature(xin))
+    assert np.array_equal(_np(out.indices), coords)
+    assert float((out.features.detach().cpu().double() - y_ref.detach()).abs().max()) < 2e-5
+    out.features.backward(g.float().to(dev))
+    assert float((xin.grad.cpu().double() - xc.grad).abs().max()) < 2e-5
+    assert float((inv.weight.grad.cpu().double() - w.grad).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ a13-a18
+@pytest.mark.parametrize("name", ["s1", "s2", "s4"])
+def test_window_partition_bit_exact_vs_reference(dev, golden_dir, name):
+    from openseg3d_amd.swformer import SparseWindowPartitionLayer
+    d = np.load(os.path.join(golden_dir, "window_partition.npz"))
+    st, c = int(d[name + "_stage"]), int(d[name + "_C"])
+    coords = torch.from_numpy(d[name + "_coords"]).to(dev)
+    bs = int(d[name + "_coords"][:, 0].max()) + 1
+    layer = SparseWindowPartitionLayer(refcfg.BATCHING_INFO[st], refcfg.WINDOW_SHAPE,
+                                       (refcfg.GRID_CART / (2 ** st)).tolist())
+    plan = layer.plan(coords, bs, c, want_debug=True)
+    for s in range(2):
+        wi = plan.index[s]
+        win = d[f"{name}_win{s}"]
+        assert np.array_equal(_np(wi.win_id), win)
+        assert np.array_equal(_np(wi.in_win), d[f"{name}_inwin{s}"])
+        assert np.array_equal(_np(wi.level), d[f"{name}_level{s}"])
+        assert np.array_equal(_np(wi.slot), d[f"{name}_slot{s}"])  # conti_window * max_tokens + stable rank
+        # CSR: windows in ascending id order, tokens in ascending row order
+        uniq, cnt = np.unique(win, return_counts=True)
+        assert wi.n_windows == uniq.shape[0] and wi.n_dropped == 0
+        assert np.array_equal(_np(wi.win_count)[:wi.n_windows], cnt)
+        assert np.array_equal(_np(wi.win_start)[:wi.n_windows], np.concatenate([[0], np.cumsum(cnt)[:-1]]))
+        assert np.array_equal(_np(wi.tok)[:coords.shape[0]], np.argsort(win, kind="stable"))
+        # key-padding masks of the reference == "slot is occupied" sets
+        for bl in range(4):
+            key = f"{name}_mask{s}_l{bl}"
+            if key in d:
+                occupied = np.zeros(d[key].size, bool)
+                occupied[_np(wi.slot)[_np(wi.level) == bl]] = True
+                assert np.array_equal(~occupied.reshape(d[key].shape), d[key])
+        # sin/cos of libm vs device: <= 2 ulp of values in [-1, 1]
+        assert float(np.abs(_np(plan.pos[s]) - d[f"{name}_pos{s}"]).max()) <= 5e-7
+
+
+def test_window_partition_reports_dropped_voxels(dev):
+    from openseg3d_amd.swformer import SparseWindowPartitionLayer
+    z, y, x = np.meshgrid(np.arange(4), np.arange(10), np.arange(10), indexing="ij")
+    coords = np.stack([np.zeros(z.size), z.ravel(), y.ravel(), x.ravel()], 1).astype(np.int32)
+    info = {0: {"max_tokens": 16, "batching_range": [0, 100000]}}
+    layer = SparseWindowPartitionLayer(info, [10, 10, 8], [1440.0, 1440.0, 64.0])
+    with pytest.raises(RuntimeError, match="dropping is unsupported"):
+        layer.plan(torch.from_numpy(coords).to(dev), 1, 48)
+
+
+# ------------------------------------------------------------------------------------------ a19-a23
+def _load_block(dev, golden_dir, name):
+    from oracle import params
+    from openseg3d_amd.swformer import SparseWindowPartitionLayer, SWFormerBlock
+    d = np.load(os.path.join(golden_dir, "swformer_block.npz"))
+    st, c, depth, seed = (int(v) for v in d[name + "_meta"])
+    blk = SWFormerBlock(c, 8, depth=depth, drop_path=[0.1] * depth)
+    params.fill_by_name(blk, seed=seed)
+    blk = blk.to(dev).eval()
+    part = SparseWindowPartitionLayer(refcfg.BATCHING_INFO[st], refcfg.WINDOW_SHAPE,
+                                      (refcfg.GRID_CART / (2 ** st)).tolist())
+    coords = torch.from_numpy(d[name + "_coords"]).to(dev)
+    bs = int(d[name + "_coords"][:, 0].max()) + 1
+    return d, blk, part.plan(coords, bs, c), st, c, depth, seed
+
+
+@pytest.mark.parametrize("name", ["c48", "c96"])
+def test_swformer_block_matches_reference(dev, golden_dir, name):
+    d, blk, plan, st, c, depth, seed = _load_block(dev, golden_dir, name)
+    feats = torch.from_numpy(d[name + "_feats"]).to(dev)
+    with torch.no_grad():
+        a0 = blk.layers[0].win_attn(feats, plan.pos[0], plan.index[0])
+        y = blk({"voxel_features": feats, "plan": plan})
+    # fp32 end to end; outputs are O(1-5): 2e-5 abs is ~1e-5 relative
+    assert float(np.abs(_np(a0) - d[name + "_attn0"]).max()) < 2e-5
+    assert float(np.abs(_np(y) - d[name + "_out"]).max()) < 5e-5
+
+
+def test_window_attention_backward_vs_oracle_autograd(dev, golden_dir):
+    from oracle import params, window as W
+    d, blk, plan, st, c, depth, seed = _load_block(dev, golden_dir, "c48")
+    coords = torch.from_numpy(d["c48_coords"])
+    feats = torch.from_numpy(d["c48_feats"])
+    info = W.window_partition(coords, refcfg.BATCHING_INFO[st], refcfg.WINDOW_SHAPE, refcfg.GRID_CART / (2 ** st), c)
+    p = {k: v.double().requires_grad_() for k, v in
+         params.state_dict_for(refcfg.swformer_param_shapes(c, depth), seed).items()}
+    xr = feats.double().requires_grad_()
+    pos = {k: v.double() for k, v in info["pos_dict_shift0"].items()}
+    yr = W.window_attention(xr, pos, info["flat2win_inds_shift0"], info["key_mask_shift0"], p,
+                            "layers.0.win_attn.", 8)
+    g = torch.randn(yr.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    yr.backward(g)
+
+    attn = blk.layers[0].win_attn
+    xg = feats.to(dev).requires_grad_()
+    y = attn(xg, plan.pos[0], plan.index[0])
+    y.backward(g.float().to(dev))
+    pre = "layers.0.win_attn.self_attn."
+    checks = [(xg.grad, xr.grad), (attn.self_attn.in_proj_weight.grad, p[pre + "in_proj_weight"].grad),
+              (attn.self_attn.in_proj_bias.grad, p[pre + "in_proj_bias"].grad),
+              (attn.self_attn.tau.grad, p[pre + "tau"].grad),
+              (attn.self_attn.out_proj.weight.grad, p[pre + "out_proj.weight"].grad)]
+    for got, ref in checks:
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got.cpu().double() - ref).abs().max()) < 2e-4 * scale
+
+
+# ------------------------------------------------------------------------------------------ a7, a24-a26
+def test_segment_reduce_and_gather(dev):
+    from oracle import sparse_conv as sc
+    from openseg3d_amd import ops
+    rs = np.random.RandomState(0)
+    n, m = 30000, 9000
+    ids = rs.randint(0, m, n).astype(np.int64)
+    ids[rs.rand(n) < 0.1] = -1
+    ids[ids == 17] = 18  # an empty segment
+    for c in (64, 6):
+        x = torch.randn(n, c)
+        idt = torch.from_numpy(ids)
+        ok = idt != -1
+        for mode in ("max", "mean"):
+            xg = x.to(dev).requires_grad_()
+            seg = ops.SegmentIndex(idt.to(dev), m)
+            out = ops.segment_reduce(xg, seg, {"max": ops.REDUCE_MAX, "mean": ops.REDUCE_MEAN}[mode])
+            xr = x.double().requires_grad_()
+            ref = sc.scatter(xr[ok], idt[ok], reduce=mode, dim_size=m)
+            tol = 0.0 if mode == "max" else 1e-6
+            assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= tol
+            g = torch.randn(m, c, dtype=torch.float64)
+            ref.backward(g)
+            out.backward(g.float().to(dev))
+            assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-6
+        # torch_scatter-shaped entry (rows = index.max()+1)
+        out = ops.scatter(x.to(dev)[ok.to(dev)], idt.to(dev)[ok.to(dev)], dim=0, reduce="max")
+        assert out.shape[0] == int(ids.max()) + 1
+    feats = torch.randn(m, 32)
+    fg = feats.to(dev).requires_grad_()
+    out = ops.voxel_to_point(fg, torch.from_numpy(ids).to(dev))
+    fr = feats.double().requires_grad_()
+    ref = sc.voxel_to_point(fr, torch.from_numpy(ids))
+    assert torch.equal(out.detach().cpu().double(), ref.detach())
+    g = torch.randn(n, 32, dtype=torch.float64)
+    ref.backward(g)
+    out.backward(g.float().to(dev))
+    assert float((fg.grad.cpu().double() - fr.grad).abs().max()) <= 1e-5
+    cnt = torch.bincount(torch.from_numpy(ids[ids >= 0]), minlength=m).int()
+    avg = ops.voxel_avg_pooling(x.to(dev), torch.from_numpy(ids).int().to(dev), cnt.to(dev))
+    assert float((avg.cpu() - sc.voxel_avg_pooling(x, torch.from_numpy(ids).int(), cnt)).abs().max()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------ whole path
+def _build_model(dev, cyl):
+    from oracle import params
+    from openseg3d_amd import config, segformer
+    cfg = config.default_cfg()
+    if cyl:
+        cfg.DATASET.USE_CYLINDER = True
+        cfg.DATASET.POINT_CLOUD_RANGE = refcfg.CYL_RANGE
+        cfg.DATASET.VOXEL_SIZE = refcfg.CYL_VOXEL
+    ds = config.DatasetSpec(cfg)
+    model = segformer.build_segmentor(cfg, ds)
+    params.fill_by_name(model, seed=0)
+    return model.to(dev).eval(), cfg, ds
+
+
+@pytest.mark.parametrize("tag,cyl", [("cart", False), ("cyl", True)])
+def test_segformer_logits_match_reference_model(dev, golden_dir, tag, cyl):
+    """north_star bar: per-point logits within 1e-3 of the reference forward (eval mode)."""
+    d = np.load(os.path.join(golden_dir, f"segformer_{tag}.npz"))
+    model, cfg, ds = _build_model(dev, cyl)
+    keys = json.load(open(os.path.join(golden_dir, "segformer_keys.json")))
+    sd = model.state_dict()
+    assert set(sd) == set(keys)
+    batch = {"points": torch.from_numpy(d["points"]).to(dev), "voxel_coords": torch.from_numpy(d["voxel_coords"]).to(dev),
+             "point_voxel_ids": torch.from_numpy(d["point_voxel_ids"]).to(dev),
+             "point_id_offset": torch.from_numpy(d["point_id_offset"]).to(dev), "batch_size": int(d["batch_size"])}
+    with torch.no_grad():
+        res = model(batch)
+    assert np.array_equal(_np(res["aux_voxel_coords"]), d["aux_voxel_coords"])
+    assert np.array_equal(_np(res["voxel_coords"]), d["voxel_coords"].astype(np.int32))
+    for k in ("point_out", "voxel_out", "aux_voxel_out"):
+        err = float(np.abs(_np(res[k]) - d[k]).max())
+        assert err < 1e-3, (k, err)
+
+
+def test_segformer_from_raw_points_matches_oracle(dev):
+    """End to end from raw points (GPU voxelizer + model) against the oracle on a fresh seeded scene."""
+    from oracle import index_ops, model as omodel
+    from openseg3d_amd import batch as B, scene
+    model, cfg, ds = _build_model(dev, False)
+    samples = [scene.make_small_scene(77, 5000, extent=9.0), scene.make_scene(3)[::40]]
+    b = B.make_batch(samples, ds.voxel_size, ds.point_cloud_range)
+    with torch.no_grad():
+        res = model(dict(b))
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items() if k != "point_voxel_index"}
+    ocfg = {"grid_size": index_ops.grid_size_of(ds.voxel_size, ds.point_cloud_range),
+            "batching_info": refcfg.BATCHING_INFO, "window_shape": refcfg.WINDOW_SHAPE, "depths": refcfg.DEPTHS}
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = omodel.segformer_forward(cpu, sd, ocfg)
+    for k in ("point_out", "voxel_out", "aux_voxel_out"):
+        err = float((res[k].cpu() - ref[k]).abs().max())
+        assert err < 1e-3, (k, err)

@@ -1,0 +1,102 @@
+"""Host-side logic that needs no GPU: config loading, model construction / state_dict contract,
+window geometry, the synthetic scene generator."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import refcfg
+
+YAML_CYL = """
+DATASET:
+  USE_CYLINDER: True
+  POINT_CLOUD_RANGE: [0, -3.1415926, -2, 75.2, 3.1415926, 5.2]
+  VOXEL_SIZE: [0.05, 0.012, 0.1]
+  CLASS_NAMES: ['Car', 'Truck']
+TRAIN:
+  LR: 0.05
+  OPTIMIZER: 'sgd'
+  WEIGHT_DECAY: 0.0001
+  MOMENTUM: 0.9
+"""
+
+
+def test_yaml_merges_like_the_reference(tmp_path):
+    from openseg3d_amd import config
+    p = tmp_path / "c.yaml"
+    p.write_text(YAML_CYL)
+    cfg = config.cfg_from_file(str(p))
+    assert cfg.DATASET.USE_CYLINDER is True and cfg.DATASET.VOXEL_SIZE == [0.05, 0.012, 0.1]
+    assert cfg.TRAIN.OPTIMIZER == "sgd" and cfg.MODEL.SEGMENTOR == "segformer"
+    assert cfg.MODEL.BATCHING_INFO[0]["3"]["max_tokens"] == 800
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("DATASET:\n  NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError):
+        config.cfg_from_file(str(bad))
+    bad.write_text("TRAIN:\n  LR: 'fast'\n")
+    with pytest.raises(ValueError):
+        config.cfg_from_file(str(bad))
+
+
+def test_default_batching_info_equals_reference_defaults():
+    from openseg3d_amd import config
+    cfg = config.default_cfg()
+    got = [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO]
+    assert got == refcfg.BATCHING_INFO
+    assert cfg.MODEL.WINDOW_SHAPE == refcfg.WINDOW_SHAPE and cfg.MODEL.DEPTHS == refcfg.DEPTHS
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+def test_state_dict_contract(golden_dir, cyl):
+    """Same keys and shapes as the reference Segformer (list written by make_golden.py)."""
+    from openseg3d_amd import config, segformer
+    cfg = config.default_cfg()
+    if cyl:
+        cfg.DATASET.USE_CYLINDER = True
+        cfg.DATASET.POINT_CLOUD_RANGE, cfg.DATASET.VOXEL_SIZE = refcfg.CYL_RANGE, refcfg.CYL_VOXEL
+    ds = config.DatasetSpec(cfg)
+    assert ds.grid_size.tolist() == (refcfg.GRID_CYL if cyl else refcfg.GRID_CART).tolist()
+    model = segformer.build_segmentor(cfg, ds)
+    keys = refcfg.segformer_key_shapes(json.load(open(os.path.join(golden_dir, "segformer_keys.json"))), 8 if cyl else 6)
+    sd = model.state_dict()
+    assert set(sd) == set(keys)
+    assert all(list(sd[k].shape) == list(keys[k]) for k in keys)
+    assert abs(sum(p.numel() for p in model.parameters()) - 32.93e6) < 0.05e6
+
+
+def test_unsupported_configs_are_refused():
+    from openseg3d_amd import config, segformer
+    cfg = config.default_cfg()
+    cfg.DATASET.USE_MULTI_SWEEPS = True
+    with pytest.raises(NotImplementedError):
+        segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    cfg = config.default_cfg()
+    cfg.MODEL.SEGMENTOR = "spnet"
+    with pytest.raises(NotImplementedError):
+        segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+
+
+def test_window_geometry_matches_reference_quirks():
+    from openseg3d_amd.swformer import window_geometry
+    # stage 1 of the cartesian grid: 145 x 145 x 9 windows, full-window "no shift" offset (quirk 4)
+    assert window_geometry([1440, 1440, 64], [10, 10, 8], False) == ([10, 10, 8], [145, 145, 9], [10, 10, 8])
+    assert window_geometry([1440, 1440, 64], [10, 10, 8], True) == ([10, 10, 8], [145, 145, 9], [5, 5, 4])
+    # stage 4: S_z == win_z -> z never shifted (quirk 3)
+    assert window_geometry([180, 180, 8], [10, 10, 8], True)[2] == [5, 5, 0]
+    assert window_geometry([180, 180, 8], [10, 10, 8], False)[2] == [10, 10, 0]
+    # cylinder stage 4 gets a fractional shape (quirk 2): only ceil(S/win)+1 is used
+    assert window_geometry([188.0, 65.5, 9.0], [10, 10, 8], False)[1] == [20, 8, 3]
+
+
+def test_synthetic_scene_is_waymo_shaped_and_seeded():
+    from openseg3d_amd import scene
+    from oracle import index_ops
+    a, b = scene.make_scene(0), scene.make_scene(0)
+    assert a.dtype == np.float32 and a.shape[1] == 6 and np.array_equal(a, b)
+    assert 150_000 < a.shape[0] < 200_000
+    assert not np.array_equal(a[:100], scene.make_scene(1)[:100])
+    coors, ids = index_ops.voxelize(a, refcfg.CART_VOXEL, refcfg.CART_RANGE)
+    assert 60_000 < coors.shape[0] < 140_000 and (ids >= 0).mean() > 0.95
+    assert scene.cart2polar_rows(a).shape == (a.shape[0], 8)
