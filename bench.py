@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Benchmark of the sparse-voxel segmentation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode fwd|fwdbwd] [--scenes S]
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU: GPU voxelisation of
+a resident Waymo-shaped scene (~180 k float32 points, 0.1 m voxels, grid 1440x1440x64, i.e.
+configs/waymo_one_sweep.yaml = BASELINE.json configs[1]) followed by Segformer forward
+(mode fwd, eval) or forward + loss + backward + optimizer step (mode fwdbwd, train; gradients
+all-reduced over RCCL when N > 1).  Scenes shard data-parallel: every rank processes its own scenes,
+`value` = points processed by all ranks / max-over-ranks wall time ("scaling": "weak").
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     -- the dominant kernel (sparse-conv gather-GEMM): algorithmic bytes / live HIP-event time
+  cpu_baseline -- the CPU oracle (port of the reference algorithm) timed on the host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["fwd", "fwdbwd"], default="fwd")
+    ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
+    ap.add_argument("--batch", type=int, default=1, help="scenes per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU-baseline sample (0 = whole scene)")
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+    torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def conv_roofline(model, batch, dev):
+    """One instrumented forward: HIP events around every seg3d_spconv_fwd launch (same stream)."""
+    from openseg3d_amd import ops
+    records = []
+    orig = ops._conv_apply
+
+    def timed(x, nbr, w_packed, bias, cin, cout):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig(x, nbr, w_packed, bias, cin, cout)
+        e1.record()
+        records.append((nbr, cin, cout, e0, e1))
+        return y
+
+    ops._conv_apply = timed
+    try:
+        with torch.no_grad():
+            model(dict(batch))
+        torch.cuda.synchronize()
+    finally:
+        ops._conv_apply = orig
+    pairs_cache, tot_bytes, tot_ms = {}, 0.0, 0.0
+    per_layer = []
+    for nbr, cin, cout, e0, e1 in records:
+        key = nbr.data_ptr()
+        if key not in pairs_cache:
+            pairs_cache[key] = int((nbr >= 0).sum().item())
+        p = pairs_cache[key]
+        algo = p * (cin + cout) * 4 + 27 * cin * cout * 4 + p * 8
+        ms = e0.elapsed_time(e1)
+        tot_bytes += algo
+        tot_ms += ms
+        per_layer.append({"rows": int(nbr.shape[1]), "pairs": p, "cin": cin, "cout": cout, "us": round(ms * 1e3, 1),
+                          "GBs": round(algo / ms / 1e6, 1)})
+    n = max(len(records), 1)
+    achieved = tot_bytes / tot_ms / 1e6 if tot_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "spconv_fwd_kernel (all sparse-conv launches of one forward)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(records),
+            "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
+
+
+def cpu_baseline(scene_np, cfg, ds, model, n_points):
+    """The oracle (CPU restatement of the reference algorithm) on the host cores: same scene (or its first
+    n_points rows), same weights, eval forward."""
+    from oracle import index_ops, model as omodel
+    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe a larger affinity mask
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle forward on {cores} host threads ...", file=sys.stderr, flush=True)
+    pts = scene_np if not n_points else scene_np[:n_points]
+    t0 = time.time()
+    coords, ids = index_ops.voxelize(pts, ds.voxel_size, ds.point_cloud_range)
+    batch = {"points": torch.from_numpy(np.pad(pts, ((0, 0), (1, 0)))).float(),
+             "voxel_coords": torch.from_numpy(np.pad(coords, ((0, 0), (1, 0)))).float(),
+             "point_voxel_ids": torch.from_numpy(ids).long(), "batch_size": 1}
+    ocfg = {"grid_size": index_ops.grid_size_of(ds.voxel_size, ds.point_cloud_range),
+            "batching_info": [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO],
+            "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS}
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        omodel.segformer_forward(batch, sd, ocfg)
+    dt = time.time() - t0
+    return {"value": round(pts.shape[0] / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"1 forward (voxelize + Segformer eval) of {pts.shape[0]} points of scene seed 0, "
+                      f"{coords.shape[0]} voxels, {dt:.1f} s, torch.set_num_threads({cores})"}
+
+
+def main():
+    args = parse()
+    rank, world, local = setup_dist(args)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    from openseg3d_amd import batch as B, config, scene, segformer
+    dev = torch.device("cuda", local)
+    cfg = config.default_cfg()  # == configs/waymo_one_sweep.yaml for every key the model path reads
+    ds = config.DatasetSpec(cfg)
+    torch.manual_seed(0)
+    model = segformer.build_segmentor(cfg, ds).to(dev)
+
+    # resident synthetic scenes: seeds differ per rank (data-parallel shards of the scene stream)
+    seeds = [rank * args.scenes * args.batch + i for i in range(args.scenes * args.batch)]
+    scenes_np = [scene.make_scene(s) for s in seeds]
+    groups = [scenes_np[i * args.batch:(i + 1) * args.batch] for i in range(args.scenes)]
+    resident = [B.collate_points(g, dev) for g in groups]
+    offsets = [np.cumsum([s.shape[0] for s in g]).tolist() for g in groups]
+    pts_per_step = [int(r.shape[0]) for r in resident]
+
+    train = args.mode == "fwdbwd"
+    if train:
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)  # configs/waymo_one_sweep.yaml
+        net = model
+        if world > 1:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
+        labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
+    else:
+        model.eval()
+        net = model
+
+    def step(i):
+        j = i % len(resident)
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range)
+        if not train:
+            with torch.no_grad():
+                return net(b)
+        opt.zero_grad(set_to_none=True)
+        res = net(b)
+        ce = torch.nn.functional.cross_entropy
+        vox_lab = labels[j][:1].expand(res["voxel_out"].shape[0])  # constant voxel labels: loss plumbing only
+        aux_lab = labels[j][:1].expand(res["aux_voxel_out"].shape[0])
+        loss = ce(res["point_out"], labels[j]) + ce(res["voxel_out"], vox_lab) + 0.4 * ce(res["aux_voxel_out"], aux_lab)
+        loss.backward()
+        opt.step()
+        return res
+
+    for i in range(args.warmup):
+        step(i)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    n_pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
+
+    stats = torch.tensor([dt, float(n_pts)], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        psum = stats[1:].clone()
+        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        dt, n_pts = float(tmax.item()), float(psum.item())
+
+    out = None
+    if rank == 0:
+        model.eval()
+        b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range)
+        roof, per_layer = conv_roofline(model, b0, dev)
+        out = {
+            "metric": "points/sec fwd+bwd, Waymo 1-sweep ~180k pts @0.1m voxel; logit parity",
+            "value": round(n_pts / dt, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "waymo_one_sweep (BASELINE configs[1]): synthetic 64-beam scene, "
+                                   f"{pts_per_step[0]} pts/step/GPU, voxel 0.1 m, grid 1440x1440x64, "
+                                   f"{'forward-only eval' if not train else 'fwd+loss+bwd+SGD step'}",
+                       "mode": args.mode, "scenes_per_step_per_gpu": args.batch,
+                       "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scenes_np[0], cfg, ds, model, args.cpu_points)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
+            json.dump(per_layer, f, indent=1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

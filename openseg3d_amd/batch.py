@@ -15,19 +15,24 @@ def collate_points(samples, device):
     """list of [N_i, D] arrays -> float32 [sum N, 1+D] with the batch index in column 0."""
     rows = [np.concatenate([np.full((s.shape[0], 1), b, dtype=s.dtype), s], axis=1) for b, s in enumerate(samples)]
     pts = torch.from_numpy(np.ascontiguousarray(np.concatenate(rows, axis=0)))
-    return pts.to(device=device, non_blocking=True)
+    return pts.to(device=device)
+
+
+def batch_from_resident(points, row_offsets, voxel_size, point_cloud_range):
+    """points: collated [sum N, 1+D] tensor already in HBM; row_offsets: cumulative rows per sample (ints)."""
+    coords, ids = ops.voxelize(points, voxel_size, point_cloud_range, xyz_col=1, batch_col=0)
+    return {
+        "points": points if points.dtype == torch.float32 else points.float(),
+        "voxel_coords": coords.float(),
+        "point_voxel_ids": ids.long(),
+        "point_id_offset": torch.tensor(row_offsets, dtype=torch.float32, device=points.device),
+        "point_row_offsets": [int(o) for o in row_offsets],
+        "point_voxel_index": ops.SegmentIndex(ids, coords.shape[0]),
+        "batch_size": len(row_offsets),
+    }
 
 
 def make_batch(samples, voxel_size, point_cloud_range, device="cuda"):
     pts = collate_points(samples, device)
-    coords, ids = ops.voxelize(pts, voxel_size, point_cloud_range, xyz_col=1, batch_col=0)
     offsets = np.cumsum([s.shape[0] for s in samples]).tolist()
-    return {
-        "points": pts.float(),
-        "voxel_coords": coords.float(),
-        "point_voxel_ids": ids.long(),
-        "point_id_offset": torch.tensor(offsets, dtype=torch.float32, device=device),
-        "point_row_offsets": [int(o) for o in offsets],
-        "point_voxel_index": ops.SegmentIndex(ids, coords.shape[0]),
-        "batch_size": len(samples),
-    }
+    return batch_from_resident(pts, offsets, voxel_size, point_cloud_range)

@@ -93,10 +93,9 @@ def scatter(src, index, reduce="mean", dim_size=None):
             out = out / cnt[:, None]
         return out
     if reduce == "max":
-        out.fill_(float("-inf"))
-        out.index_reduce_(0, index, src, "amax", include_self=True)
-        out[torch.isinf(out) & (out < 0)] = 0
-        return out
+        neg = torch.full_like(out, float("-inf"))
+        red = neg.index_reduce(0, index, src, "amax", include_self=True)
+        return torch.where(torch.isinf(red) & (red < 0), torch.zeros_like(red), red)
     raise NotImplementedError(reduce)
 
 
