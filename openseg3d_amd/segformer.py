@@ -64,13 +64,15 @@ class FlattenSELayer(nn.Module):
     def forward(self, x, indices, row_offsets=None):
         """``row_offsets`` (python ints, cumulative rows per sample) lets the mean run on contiguous slices --
         samples are contiguous after collate_batch -- instead of a scatter over <= batch_size huge segments."""
-        indices = indices.long()
         if row_offsets is not None:
             starts = [0] + list(row_offsets[:-1])
-            pooled = torch.stack([x[s:e].mean(dim=0) if e > s else x.new_zeros(x.shape[1])
-                                  for s, e in zip(starts, row_offsets)])
-        else:
-            pooled = ops.scatter(x, indices, reduce="mean")
+            spans = [(s, e) for s, e in zip(starts, row_offsets)]
+            pooled = torch.stack([x[s:e].mean(dim=0) if e > s else x.new_zeros(x.shape[1]) for s, e in spans])
+            gate = self.fc(pooled)
+            # broadcast per contiguous sample: the backward is a row sum, not an index_put over N rows
+            return torch.cat([x[s:e] * gate[b] for b, (s, e) in enumerate(spans)], dim=0)
+        indices = indices.long()
+        pooled = ops.scatter(x, indices, reduce="mean")
         return x * self.fc(pooled)[indices]
 
 
