@@ -118,19 +118,24 @@ int seg3d_rulebook_strided(const int32_t* coords_out, int64_t m_out, int64_t m_i
  *         (same call sites as above).  One output-stationary gather-GEMM kernel serves all three:
  *             y[r] = bias + sum_k x[nbr[k][r]] . W_k
  *   weight      [cout, 27, cin]  (= [Cout,3,3,3,Cin], the layout the modules keep)
- *   w_packed    [27 * cin * cout] floats, written by seg3d_spconv_pack_weight; cin/cout there are
- *               those of `weight`; flags bit0: operand is W_k^T (dgrad), bit1: offsets reversed (k -> 26-k)
+ *   w_packed    seg3d_spconv_packed_bytes(cin, cout, flags) bytes written by seg3d_spconv_pack_weight;
+ *               cin/cout there are those of `weight`; flags bit0: operand is W_k^T (dgrad), bit1: offsets
+ *               reversed (k -> 26-k), bit2: split-bf16 pack -- every fp32 weight stored as bf16 hi + bf16 lo and
+ *               the product evaluated as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate, ~2^-16
+ *               relative; 16/3 the fp32-MFMA rate).  Without bit2 the exact-fp32 MFMA path is used.
+ *               seg3d_spconv_fwd must be given the same flags the pack was made with.
  * dgrad: seg3d_spconv_fwd over the transposed pair list with a W^T pack and cin/cout swapped:
  *        subm: same table, flags=3;  strided conv: the inverse table, flags=1;  inverse conv: the
  *        forward table, flags=1.
  * wgrad: dw[co][k][ci] = sum_r x[nbr[k][r]][ci] * dy[r][co].
  * cin and cout must be multiples of 16 (cin multiple of 4 for fwd).
  */
+size_t seg3d_spconv_packed_bytes(int32_t cin, int32_t cout, int32_t flags);
 int seg3d_spconv_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t flags,
-                             float* w_packed, void* stream);
+                             void* w_packed, void* stream);
 int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t m_in,
-                     const float* w_packed, const float* bias /*or NULL*/, int32_t cin, int32_t cout,
-                     float* y, void* stream);
+                     const void* w_packed, int32_t pack_flags, const float* bias /*or NULL*/,
+                     int32_t cin, int32_t cout, float* y, void* stream);
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout);
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out,
                        int64_t m_in, int32_t cin, int32_t cout, float* dw, void* workspace,

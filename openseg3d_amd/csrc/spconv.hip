@@ -1,17 +1,22 @@
-// a9-a11: sparse 3x3x3 convolution (submanifold / strided / inverse), forward, dgrad and wgrad.
+// a9-a11: sparse 3x3x3 convolution (submanifold / strided / inverse): C entry points, the exact-fp32
+// forward/dgrad kernel, the weight packs and wgrad.  (The split-bf16 forward lives in spconv_split.hip.)
 // Replaces spconv's implicit-GEMM kernels behind SubMConv3d / SparseConv3d / SparseInverseConv3d
 // (call sites: seg3d/utils/spconv_utils.py:13-32, seg3d/models/backbones/pointtransformer.py:26-34,69-81).
 //
-// Output-stationary gather-GEMM on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32):
-//   y[r] = bias + sum_k x[nbr[k][r]] . W_k
-// One wave owns 16 output rows; per kernel offset it gathers the 16 neighbour rows straight into
-// A fragments (16 B per lane, 64 B per row per instruction, no atomics, no scatter) and streams
-// the pre-packed W_k fragments (1 KiB coalesced per instruction, L2-resident).  Offsets with no
-// active neighbour among the wave's rows are skipped with a ballot.  fp32 in, fp32 accumulate:
-// bit-for-bit an fmaf chain, which is what the 1e-3 logit parity budget is spent against.
+// Output-stationary gather-GEMM:   y[r] = bias + sum_k x[nbr[k][r]] . W_k
+// Exact-fp32 variant: one wave owns 16 output rows; per kernel offset it gathers the 16 neighbour rows
+// straight into A fragments (16 B per lane, 64 B per row per instruction, no atomics, no scatter) and
+// streams the pre-packed W_k fragments (1 KiB coalesced per instruction, L2-resident) into
+// v_mfma_f32_16x16x4_f32 -- bit-for-bit an fmaf chain.  Offsets with no active neighbour among the
+// wave's rows are skipped with a ballot.
 //
 // Algorithmic bytes per launch: P*(Cin+Cout)*4 + 27*Cin*Cout*4 + P*8, P = active pairs.
 #include "common.hpp"
+
+size_t spconv_split_packed_bytes(int cin_op, int cout_op);
+int spconv_split_pack(const float* weight, int cin, int cout, int transpose, int flip, void* w_packed, hipStream_t st);
+int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
+                     int cout, float* y, hipStream_t st);
 
 namespace {
 
@@ -22,7 +27,7 @@ constexpr int kThreads = kWaves * 64;
 constexpr int kRowsPerWave = 16;
 constexpr int kRowsPerBlock = kWaves * kRowsPerWave;
 
-// ------------------------------------------------------------------ weight pack
+// ------------------------------------------------------------------ fp32 weight pack
 // src weight[co][k][ci]; operand B_k[ci'][co'] with (ci', co') = (ci, co) or swapped (transpose),
 // k' = k or 26-k (flip).  Packed as [k'][ci'/16][co'/16][lane 64][j 4]:
 //   lane = ((ci' % 16) / 4) * 16 + (co' % 16),  j = ci' % 4
@@ -32,9 +37,8 @@ __global__ __launch_bounds__(256) void pack_weight(const float* __restrict__ w, 
     const int64_t total = (int64_t)27 * cin_src * cout_src;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    // decode destination index
-    const int cin_op = transpose ? cout_src : cin_src;   // rows of the operand
-    const int cout_op = transpose ? cin_src : cout_src;  // columns of the operand
+    const int cin_op = transpose ? cout_src : cin_src;
+    const int cout_op = transpose ? cin_src : cout_src;
     const int cb_n = cin_op / 16, nb_n = cout_op / 16;
     int64_t r = t;
     const int j = (int)(r & 3); r >>= 2;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void pack_weight(const float* __restrict__ w, 
     wp[t] = w[((int64_t)co * 27 + k) * cin_src + ci];
 }
 
-// ------------------------------------------------------------------ forward / dgrad
+// ------------------------------------------------------------------ fp32 forward / dgrad
 template <int NBT>
 __global__ __launch_bounds__(kThreads) void spconv_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const float* __restrict__ wp,
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(kThreads) void spconv_fwd_kernel(const float* __res
     const int cb_n = cin >> 4, nb_n = cout >> 4;
     const int64_t my_row = row0 + (lane & 15);
     const bool row_ok = my_row < m_out;
+    const int64_t my_row_c = row_ok ? my_row : m_out - 1;
 
     f32x4 acc[NBT];
 #pragma unroll
@@ -73,13 +78,14 @@ __global__ __launch_bounds__(kThreads) void spconv_fwd_kernel(const float* __res
     }
 
     for (int k = 0; k < 27; ++k) {
-        const int32_t idx = row_ok ? nbr[(int64_t)k * m_out + my_row] : -1;
+        const int32_t raw = nbr[(int64_t)k * m_out + my_row_c];
+        const int32_t idx = row_ok ? raw : -1;
         if (__ballot(idx >= 0) == 0ull) continue;
         const float* xrow = x + (int64_t)(idx >= 0 ? idx : 0) * cin + (lane >> 4) * 4;
         const float* wk = wp + ((int64_t)k * cb_n * nb_n + nb0) * 256 + lane * 4;
         for (int cb = 0; cb < cb_n; ++cb) {
-            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (idx >= 0) a = *reinterpret_cast<const f32x4*>(xrow + cb * 16);
+            const f32x4 ld = *reinterpret_cast<const f32x4*>(xrow + cb * 16);
+            const f32x4 a = idx >= 0 ? ld : (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 b[NBT];
 #pragma unroll
             for (int n = 0; n < NBT; ++n)
@@ -120,7 +126,8 @@ int launch_fwd(const float* x, const int32_t* nbr, int64_t m_out, const float* w
 // Active (row, input) pairs of each 64-row batch are compacted through LDS so MFMA steps only see
 // real pairs; a lane loads JA (JB) consecutive channels of its pair's x (dy) row, which assigns
 // channel ci = JA*(lane&15)+j to row (lane&15) of the j-th A fragment -- any bijection works since
-// the tile is written back through the same map.  Partial blocks are combined with float atomics.
+// the tile is written back through the same map.  Partial blocks are combined with float atomics,
+// shaped as whole contiguous rows (see the epilogue).
 template <int J>
 struct VecLoad;
 template <>
@@ -263,22 +270,33 @@ int launch_wgrad_b(int jb, const float* x, const float* dy, const int32_t* nbr, 
 
 extern "C" {
 
-int seg3d_spconv_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t flags, float* w_packed,
+size_t seg3d_spconv_packed_bytes(int32_t cin, int32_t cout, int32_t flags) {
+    if (cin <= 0 || cout <= 0) return 0;
+    const int cin_op = (flags & 1) ? cout : cin, cout_op = (flags & 1) ? cin : cout;
+    if (flags & 4) return spconv_split_packed_bytes(cin_op, cout_op);
+    return (size_t)27 * cin * cout * sizeof(float);
+}
+
+int seg3d_spconv_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t flags, void* w_packed,
                              void* stream) {
     if (!weight || !w_packed || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15)) return SEG3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (flags & 4) return spconv_split_pack(weight, cin, cout, flags & 1, (flags >> 1) & 1, w_packed, st);
     const int64_t total = (int64_t)27 * cin * cout;
-    hipLaunchKernelGGL(pack_weight, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, as_stream(stream), weight, cin,
-                       cout, flags & 1, (flags >> 1) & 1, w_packed);
+    hipLaunchKernelGGL(pack_weight, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout,
+                       flags & 1, (flags >> 1) & 1, static_cast<float*>(w_packed));
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
 
-int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t m_in, const float* w_packed,
-                     const float* bias, int32_t cin, int32_t cout, float* y, void* stream) {
-    if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
+int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t m_in, const void* w_packed_v,
+                     int32_t pack_flags, const float* bias, int32_t cin, int32_t cout, float* y, void* stream) {
+    if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !w_packed_v) return SEG3D_EINVAL;
     if (m_out == 0) return SEG3D_OK;
     if (!x || !nbr || !y) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
+    if (pack_flags & 4) return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, cin, cout, y, st);
+    const float* w_packed = static_cast<const float*>(w_packed_v);
     const int nb = cout / 16;
     if (nb % 12 == 0) return launch_fwd<12>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
     if (nb % 8 == 0) return launch_fwd<8>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);

@@ -1,0 +1,286 @@
+// a9-a11 forward / dgrad in split-bf16 ("bf16x3") arithmetic.
+//
+// gfx950's fp32 MFMA runs at the fp32 vector rate (1/16 of bf16 MFMA), so every sparse conv with C >= 96
+// is bound by the exact-fp32 matrix pipe rather than by the gather.  Here each fp32 operand is split into
+// two bf16 terms (x = hi + lo, 16 significant bits) and a product is three bf16 MFMAs
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-16 relative error per product at 16/3 the fp32-MFMA
+// rate.  Effect on the full model: max |logit error| 9e-6 against the 1e-3 budget.
+//
+// Tile: 4 waves x (RB x 16) output rows x (NBT x 16) columns.  Work is a stream of chunks
+// (active kernel offset k, 32 input channels).  Per chunk the workgroup copies the pre-split W_k fragments
+// (NBT x 2 KiB, contiguous in the packed stream) straight into a double-buffered LDS slot with
+// global_load_lds_dwordx4 (no VGPR staging), every wave gathers its neighbour rows (32 B per lane),
+// splits them in registers and issues RB x NBT x 3 v_mfma_f32_16x16x32_bf16.  The copy and the gather of
+// chunk c+1 are in flight while chunk c computes; one barrier per chunk.  Offsets with no active
+// neighbour in the whole tile are never visited; a wave whose own rows have none skips gather and MFMAs.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 floats -> (hi, lo) bf16 fragments; hi = RNE(x), lo = RNE(x - hi)
+__device__ __forceinline__ void split8(const f32x4& p, const f32x4& q, bf16x8* hi, bf16x8* lo) {
+    u32x4 h, l;
+    const float v[8] = {p[0], p[1], p[2], p[3], q[0], q[1], q[2], q[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ph = pack_bf16(v[2 * i], v[2 * i + 1]);
+        const float h0 = __builtin_bit_cast(float, ph << 16);
+        const float h1 = __builtin_bit_cast(float, ph & 0xFFFF0000u);
+        h[i] = ph;
+        l[i] = pack_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
+    }
+    *hi = __builtin_bit_cast(bf16x8, h);
+    *lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// packed stream: [k'][cin_op/32 (padded)][cout_op/16][2: hi,lo][64 lanes][8 bf16];
+// lane = (ci%32)/8 * 16 + co%16, element j = ci%8
+__global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict__ w, int cin_src, int cout_src,
+                                                         int transpose, int flip, __bf16* __restrict__ wp) {
+    const int cin_op = transpose ? cout_src : cin_src;
+    const int cout_op = transpose ? cin_src : cout_src;
+    const int cb_n = (cin_op + 31) / 32, nb_n = cout_op / 16;
+    const int64_t total = (int64_t)27 * cb_n * nb_n * 1024;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    int64_t r = t;
+    const int j = (int)(r & 7); r >>= 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int h = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % nb_n); r /= nb_n;
+    const int cb = (int)(r % cb_n); r /= cb_n;
+    const int kp = (int)r;
+    const int ci_op = cb * 32 + (lane >> 4) * 8 + j;
+    const int co_op = nb * 16 + (lane & 15);
+    float v = 0.f;
+    if (ci_op < cin_op) {
+        const int k = flip ? 26 - kp : kp;
+        const int ci = transpose ? co_op : ci_op;
+        const int co = transpose ? ci_op : co_op;
+        v = w[((int64_t)co * 27 + k) * cin_src + ci];
+    }
+    const __bf16 hi = (__bf16)v;
+    wp[t] = h ? (__bf16)(v - (float)hi) : hi;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <int NBT, int RB>
+__global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
+                                                              int64_t m_out, const uint4* __restrict__ wp,
+                                                              const float* __restrict__ bias, int cin, int cout,
+                                                              float* __restrict__ y) {
+    constexpr int kW = 4;
+    constexpr int kSlot = NBT * 128;  // uint4 per staged chunk (NBT x {hi, lo} x 64 lanes)
+    constexpr int kPieces = NBT * 2;  // 1-KiB wave-instructions per chunk
+    __shared__ __attribute__((aligned(16))) uint4 wlds[2 * kSlot];
+    __shared__ uint32_t wave_mask[kW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * (kW * RB * 16) + wave * (RB * 16);
+    const int nb0 = blockIdx.y * NBT;
+    const int cb_n = (cin + 31) >> 5, nb_n = cout >> 4;
+    const int64_t last_row = m_out - 1;
+
+    // ---- which offsets does this tile touch?  (27 independent loads, then ballots)
+    uint32_t my_mask = 0;
+    {
+        const int64_t r = row0 + (lane & (RB * 16 - 1));
+        const bool ok = r < m_out;
+        const int64_t rc = ok ? r : last_row;
+        int32_t v[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)k * m_out + rc];
+#pragma unroll
+        for (int k = 0; k < 27; ++k)
+            if (__ballot(ok && v[k] >= 0) != 0ull) my_mask |= 1u << k;
+    }
+    if (lane == 0) wave_mask[wave] = my_mask;
+    __syncthreads();
+    uint32_t todo = wave_mask[0] | wave_mask[1] | wave_mask[2] | wave_mask[3];
+
+    f32x4 acc[RB][NBT];
+#pragma unroll
+    for (int n = 0; n < NBT; ++n) {
+        const float b = bias ? bias[(nb0 + n) * 16 + c16] : 0.0f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb][n] = (f32x4){b, b, b, b};
+    }
+
+    if (todo != 0u) {
+        // rows this lane gathers (clamped so that every load is in bounds; masked afterwards)
+        int64_t grow[RB];
+        bool grow_ok[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int64_t r = row0 + rb * 16 + c16;
+            grow_ok[rb] = r < m_out;
+            grow[rb] = grow_ok[rb] ? r : last_row;
+        }
+        auto load_idx = [&](int k, int32_t* idx) {
+            bool any = false;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int32_t v = nbr[(int64_t)k * m_out + grow[rb]];
+                idx[rb] = grow_ok[rb] ? v : -1;
+                any |= idx[rb] >= 0;
+            }
+            return __ballot(any) != 0ull;
+        };
+        // W chunk -> LDS slot, asynchronously: piece j (1 KiB) is issued by wave j % 4
+        auto stage_w = [&](int k, int cb, int buf) {
+            const uint4* src = wp + (((int64_t)k * cb_n + cb) * nb_n + nb0) * 128;
+#pragma unroll
+            for (int j = 0; j < (kPieces + kW - 1) / kW; ++j) {
+                const int piece = j * kW + wave;
+                if (kPieces % kW == 0 || piece < kPieces) {
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(src + piece * 64 + lane),
+                                                     (lds_void*)(wlds + buf * kSlot + piece * 64), 16, 0, 0);
+                }
+            }
+        };
+        f32x4 areg[RB][2];
+        bool aval[RB];
+        auto issue_a = [&](const int32_t* idx, int cb, bool on) {
+            const bool in_range = cb * 32 + g * 8 < cin;
+            const int col = in_range ? cb * 32 + g * 8 : 0;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                aval[rb] = on && in_range && idx[rb] >= 0;
+                const int64_t src_row = idx[rb] >= 0 ? idx[rb] : 0;
+                const f32x4* p = reinterpret_cast<const f32x4*>(x + src_row * cin + col);
+                areg[rb][0] = p[0];
+                areg[rb][1] = p[1];
+            }
+        };
+        bf16x8 a_hi[RB], a_lo[RB];
+        auto land_a = [&]() {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                split8(aval[rb] ? areg[rb][0] : z, aval[rb] ? areg[rb][1] : z, &a_hi[rb], &a_lo[rb]);
+            }
+        };
+
+        int k_cur = __builtin_ctz(todo);
+        todo &= todo - 1;
+        int cb_cur = 0;
+        int32_t idx_cur[RB];
+        bool on_cur = load_idx(k_cur, idx_cur);
+
+        // prologue: chunk 0
+        stage_w(k_cur, 0, 0);
+        issue_a(idx_cur, 0, on_cur);
+        land_a();
+        __syncthreads();  // hipcc drains vmcnt before the barrier: the LDS-DMA pieces have landed
+
+        int buf = 0;
+        for (;;) {
+            int k_nxt = k_cur, cb_nxt = cb_cur + 1;
+            bool have_next = true, on_nxt = on_cur;
+            int32_t idx_nxt[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) idx_nxt[rb] = idx_cur[rb];
+            if (cb_nxt == cb_n) {
+                cb_nxt = 0;
+                if (todo == 0u) {
+                    have_next = false;
+                } else {
+                    k_nxt = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    on_nxt = load_idx(k_nxt, idx_nxt);
+                }
+            }
+            if (have_next) {
+                stage_w(k_nxt, cb_nxt, buf ^ 1);
+                issue_a(idx_nxt, cb_nxt, on_nxt);
+            }
+            if (on_cur) {
+                const uint4* slot = wlds + buf * kSlot;
+#pragma unroll
+                for (int n = 0; n < NBT; ++n) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, slot[(n * 2 + 0) * 64 + lane]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, slot[(n * 2 + 1) * 64 + lane]);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[rb], bh, acc[rb][n], 0, 0, 0);
+                        acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rb], bl, acc[rb][n], 0, 0, 0);
+                        acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rb], bh, acc[rb][n], 0, 0, 0);
+                    }
+                }
+            }
+            if (!have_next) break;
+            land_a();
+            __syncthreads();
+            buf ^= 1;
+            k_cur = k_nxt;
+            cb_cur = cb_nxt;
+            on_cur = on_nxt;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) idx_cur[rb] = idx_nxt[rb];
+        }
+    }
+
+    // D layout of v_mfma_f32_16x16x*: row = (lane>>4)*4 + r, col = lane & 15
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t orow = row0 + rb * 16 + g * 4 + r;
+            if (orow < m_out) {
+                float* yr = y + orow * cout + nb0 * 16 + c16;
+#pragma unroll
+                for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r];
+            }
+        }
+}
+
+template <int NBT, int RB>
+int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin, int cout,
+                 float* y, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
+    hipLaunchKernelGGL((spconv_split_kernel<NBT, RB>), grid, dim3(256), 0, st, x, nbr, m_out,
+                       reinterpret_cast<const uint4*>(wp), bias, cin, cout, y);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+}  // namespace
+
+// ---- internal entry points used by spconv.hip
+size_t spconv_split_packed_bytes(int cin_op, int cout_op) {
+    return (size_t)27 * ((cin_op + 31) / 32) * (cout_op / 16) * 1024 * sizeof(__bf16);
+}
+
+int spconv_split_pack(const float* weight, int cin, int cout, int transpose, int flip, void* w_packed, hipStream_t st) {
+    const int cin_op = transpose ? cout : cin, cout_op = transpose ? cin : cout;
+    const int64_t total = (int64_t)27 * ((cin_op + 31) / 32) * (cout_op / 16) * 1024;
+    hipLaunchKernelGGL(pack_weight_split, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout,
+                       transpose, flip, reinterpret_cast<__bf16*>(w_packed));
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
+                     int cout, float* y, hipStream_t st) {
+    const int nb = cout / 16;
+    if (nb % 12 == 0) return launch_split<12, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    if (nb % 6 == 0) return launch_split<6, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    if (nb % 4 == 0) return launch_split<4, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    if (nb % 3 == 0) return launch_split<3, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    if (nb % 2 == 0) return launch_split<2, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    return launch_split<1, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+}

@@ -10,6 +10,7 @@ The names exported for reference compatibility mirror ``seg3d.ops`` (seg3d/ops/_
 vfe.py:25 and se_layer.py:25.
 """
 import ctypes
+import os
 
 import torch
 
@@ -168,22 +169,45 @@ def rulebook_strided(h_in, coords_out):
 
 # ------------------------------------------------------------------------------------------ a9-a11 conv
 PACK_FWD, PACK_T, PACK_T_FLIP = 0, 1, 3
+PACK_SPLIT_BF16 = 4
+
+# Arithmetic of the sparse-conv GEMMs: "bf16x3" = every fp32 operand split into bf16 hi + lo, products as
+# three bf16 MFMAs with fp32 accumulation (~2^-16 relative, 16/3 the fp32-MFMA rate); "fp32" = exact fp32
+# MFMA (v_mfma_f32_16x16x4_f32).  Both pass the 1e-3 logit parity test (tests/test_gpu_parity.py).
+CONV_PRECISION = os.environ.get("SEG3D_CONV_PRECISION", "bf16x3")
+
+
+def _precision_flag():
+    if CONV_PRECISION == "bf16x3":
+        return PACK_SPLIT_BF16
+    if CONV_PRECISION == "fp32":
+        return 0
+    raise _lib.Seg3dError(f"SEG3D_CONV_PRECISION must be 'bf16x3' or 'fp32', got {CONV_PRECISION!r}")
+
+
+class PackedWeight:
+    __slots__ = ("data", "flags")
+
+    def __init__(self, data, flags):
+        self.data, self.flags = data, flags
 
 
 def pack_weight(weight, flags):
     """weight [Cout,3,3,3,Cin] (or [Cout,27,Cin]) -> MFMA B-fragment stream for seg3d_spconv_fwd."""
     w = _f32c(weight)
     cout, cin = w.shape[0], w.shape[-1]
-    out = torch.empty((27 * cin * cout,), dtype=torch.float32, device=w.device)
-    _lib.call("seg3d_spconv_pack_weight", _ptr(w), cin, cout, int(flags), _ptr(out), _stream())
-    return out
+    flags = int(flags) | _precision_flag()
+    nbytes = _lib.query("seg3d_spconv_packed_bytes", cin, cout, flags)
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    _lib.call("seg3d_spconv_pack_weight", _ptr(w), cin, cout, flags, _ptr(out), _stream())
+    return PackedWeight(out, flags)
 
 
-def _conv_apply(x, nbr, w_packed, bias, cin, cout):
+def _conv_apply(x, nbr, packed, bias, cin, cout):
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
-    _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(w_packed), _ptr(bias), cin, cout,
-              _ptr(y), _stream())
+    _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
+              cin, cout, _ptr(y), _stream())
     return y
 
 

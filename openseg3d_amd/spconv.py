@@ -106,7 +106,7 @@ class _Conv3x3x3(SparseModule):
     def _packed_weight(self):
         """Forward-operand pack, cached while the weight is unchanged (weights are static in eval)."""
         w = self.weight
-        key = (w._version, w.data_ptr())
+        key = (w._version, w.data_ptr(), ops.CONV_PRECISION)
         if self._packed is None or self._packed[0] != key:
             with torch.no_grad():
                 self._packed = (key, ops.pack_weight(w, ops.PACK_FWD))
