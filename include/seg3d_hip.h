@@ -155,7 +155,10 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
  *   slot     flat2window index = compact_window_in_level * max_tokens + rank; -1 if rank >= max_tokens
  *   tok      voxel rows grouped by window (ascending window id, ascending row inside)
  *   win_start/win_count [<= min(m, canvas)]  CSR of the non-empty windows into tok
- *   counts   device int32[2]: {number of non-empty windows, number of voxels with slot == -1}
+ *   win_tile0 [<= min(m, canvas)]  first 32-token tile of each window in the 32-padded token space
+ *   tile_item [<= m/32 + windows][2]  (window, tile) work items of the attention prepare pass
+ *   qg_item   [<= m/16 + windows][2]  (window, 16-query group) work items of the attention core
+ *   counts   device int32[4]: {non-empty windows, voxels with slot == -1, 32-token tiles, 16-query groups}
  */
 size_t seg3d_window_partition_workspace_bytes(int64_t m, int32_t batch_size, const int32_t* nwin_xyz);
 int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
@@ -163,7 +166,8 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
                            int32_t n_levels, const int32_t* level_lo, const int32_t* level_hi,
                            const int32_t* level_cap, int32_t* win_id, int32_t* in_win, int32_t* rank,
                            int32_t* level, int32_t* slot, int32_t* tok, int32_t* win_start,
-                           int32_t* win_count, int32_t* counts, void* workspace,
+                           int32_t* win_count, int32_t* win_tile0, int32_t* tile_item,
+                           int32_t* qg_item, int32_t* counts, void* workspace,
                            size_t workspace_bytes, void* stream);
 
 /* a17  SparseWindowPartitionLayer.get_pos_embed -- point_transformer_layer.py:151-203
@@ -183,15 +187,21 @@ int seg3d_pos_embed(const int32_t* in_win, int64_t m, const int32_t* win_xyz /*h
  *   out [m, heads*dh] flat voxel order (input of the out-projection); lse [m, heads] or NULL
  *   (log-sum-exp per query row, kept for the backward).  m = number of voxel rows; dh in {6,12,24,48}
  *   (8 heads on 48/96/192/384 channels, pointtransformer.py:141-157).
+ * Forward runs on the matrix cores in split-bf16 arithmetic (q, k, v, P as bf16 hi + lo, three
+ * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate and softmax): a prepare pass per 32-token tile
+ * (tile_item) and one wave per (16-query group, head) (qg_item); n_tiles / n_qgroups are counts[2..3] of
+ * seg3d_window_partition.
  * Backward takes the forward's out and lse, returns gradients w.r.t. the raw q, k, v (through the
  * normalisation) and adds the tau gradient into dtau[0] (caller zeroes it).
  */
-size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t heads);
+size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t n_tiles, int32_t heads, int32_t dh);
 int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
                           int32_t ldv, const int32_t* tok, const int32_t* win_start,
-                          const int32_t* win_count, int64_t m, int32_t n_windows, int32_t heads,
-                          int32_t dh, const float* tau, float tau_min, float* out, float* lse,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          const int32_t* win_count, const int32_t* win_tile0,
+                          const int32_t* tile_item, int32_t n_tiles, const int32_t* qg_item,
+                          int32_t n_qgroups, int64_t m, int32_t n_windows, int32_t heads, int32_t dh,
+                          const float* tau, float tau_min, float* out, float* lse, void* workspace,
+                          size_t workspace_bytes, void* stream);
 int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
                           int32_t ldv, const float* out, const float* dout, const float* lse,
                           const int32_t* tok, const int32_t* win_start, const int32_t* win_count,

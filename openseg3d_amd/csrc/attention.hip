@@ -1,4 +1,4 @@
-// a19-a21: sparse window cosine attention, variable-length (CSR) form, forward and backward.
+// a19-a21 backward: sparse window cosine attention, variable-length (CSR) form (forward: attention_mfma.hip).
 // Reference: flat2window -> CosineMultiheadAttention -> window2flat, i.e.
 //   seg3d/utils/swformer_utils.py:34-85 (scatter into padded [W,T,C] per batching level and back, in
 //   EVERY encoder layer), seg3d/models/layers/point_transformer_layer.py:233-258,
@@ -13,6 +13,8 @@
 //
 // Algorithmic FLOPs: 4 * C * sum_w n_w^2 per layer; padded flops are not credited.
 #include "common.hpp"
+
+size_t attn_mfma_workspace_bytes(int n_tiles, int heads, int dh);  // attention_mfma.hip
 
 namespace {
 
@@ -39,59 +41,6 @@ __global__ __launch_bounds__(kThreads) void rnorm_kernel(const float* __restrict
     }
     rq[t] = 1.0f / fmaxf(sqrtf(sq), kNormEps);
     rk[t] = 1.0f / fmaxf(sqrtf(sk), kNormEps);
-}
-
-template <int DH>
-__global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ v, int ldq, int ldk, int ldv,
-                                                            const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
-                                                            const int32_t* __restrict__ win_count, int heads,
-                                                            const float* __restrict__ rq, const float* __restrict__ rk,
-                                                            const float* __restrict__ tau, float tau_min,
-                                                            float* __restrict__ out, float* __restrict__ lse) {
-    const int w = blockIdx.x, h = blockIdx.y;
-    const int n = win_count[w];
-    const int qi = blockIdx.z * kThreads + threadIdx.x;
-    if ((int)(blockIdx.z * kThreads) >= n) return;
-    const int start = win_start[w];
-    const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
-    const bool active = qi < n;
-    const int my_tok = active ? tok[start + qi] : tok[start];
-
-    float qv[DH], acc[DH];
-    {
-        const float* qp = q + (int64_t)my_tok * ldq + h * DH;
-        const float s = rq[(int64_t)my_tok * heads + h] * inv_tau;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            qv[d] = qp[d] * s;
-            acc[d] = 0.f;
-        }
-    }
-    float mx = -INFINITY, sum = 0.f;
-    for (int j = 0; j < n; ++j) {
-        const int tj = tok[start + j];  // wave-uniform
-        const float* kp = k + (int64_t)tj * ldk + h * DH;
-        const float* vp = v + (int64_t)tj * ldv + h * DH;
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) s = fmaf(qv[d], kp[d], s);
-        s *= rk[(int64_t)tj * heads + h];
-        const float mn = fmaxf(mx, s);
-        const float corr = expf(mx - mn);
-        const float p = expf(s - mn);
-        sum = fmaf(sum, corr, p);
-#pragma unroll
-        for (int d = 0; d < DH; ++d) acc[d] = fmaf(acc[d], corr, p * vp[d]);
-        mx = mn;
-    }
-    if (active) {
-        const float inv = 1.0f / sum;
-        float* op = out + (int64_t)my_tok * (heads * DH) + h * DH;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) op[d] = acc[d] * inv;
-        if (lse) lse[(int64_t)my_tok * heads + h] = mx + logf(sum);
-    }
 }
 
 // pass A: lane = query.  dq (through the normalisation) and the tau gradient.
@@ -261,19 +210,6 @@ int run_rnorm(const AttnArgs& a, float* rq, float* rk, hipStream_t st) {
 }
 
 template <int DH>
-int run_fwd(const AttnArgs& a, float* ws, float* out, float* lse, hipStream_t st) {
-    float* rq = ws;
-    float* rk = ws + a.m * a.heads;
-    int rc = run_rnorm<DH>(a, rq, rk, st);
-    if (rc) return rc;
-    dim3 grid((unsigned)a.n_windows, (unsigned)a.heads, kQueryZ);
-    hipLaunchKernelGGL(attn_fwd_kernel<DH>, grid, dim3(kThreads), 0, st, a.q, a.k, a.v, a.ldq, a.ldk, a.ldv, a.tok,
-                       a.win_start, a.win_count, a.heads, rq, rk, a.tau, a.tau_min, out, lse);
-    SEG3D_CHECK_LAUNCH();
-    return SEG3D_OK;
-}
-
-template <int DH>
 int run_bwd(const AttnArgs& a, float* ws, const float* o, const float* dout, const float* lse, float* dq, float* dk,
             float* dv, int lddq, int lddk, int lddv, float* dtau, hipStream_t st) {
     float* rq = ws;
@@ -300,29 +236,11 @@ bool bad_common(const float* q, const float* k, const float* v, const int32_t* t
 
 extern "C" {
 
-size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t heads) {
-    if (m < 0 || heads <= 0) return 0;
-    return (size_t)(3 * m * heads + 64) * sizeof(float);
-}
-
-int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk, int32_t ldv,
-                          const int32_t* tok, const int32_t* win_start, const int32_t* win_count, int64_t m,
-                          int32_t n_windows, int32_t heads, int32_t dh, const float* tau, float tau_min, float* out,
-                          float* lse, void* workspace, size_t workspace_bytes, void* stream) {
-    if (m == 0 || n_windows == 0) return SEG3D_OK;
-    if (bad_common(q, k, v, tok, win_start, win_count, m, n_windows, heads, dh, tau, workspace) || !out)
-        return SEG3D_EINVAL;
-    if (workspace_bytes < seg3d_window_attn_workspace_bytes(m, heads)) return SEG3D_EWORKSPACE;
-    AttnArgs a{q, k, v, ldq, ldk, ldv, tok, win_start, win_count, n_windows, heads, m, tau, tau_min};
-    hipStream_t st = as_stream(stream);
-    float* ws = static_cast<float*>(workspace);
-    switch (dh) {
-        case 6: return run_fwd<6>(a, ws, out, lse, st);
-        case 12: return run_fwd<12>(a, ws, out, lse, st);
-        case 24: return run_fwd<24>(a, ws, out, lse, st);
-        case 48: return run_fwd<48>(a, ws, out, lse, st);
-        default: return SEG3D_EINVAL;
-    }
+size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t n_tiles, int32_t heads, int32_t dh) {
+    if (m < 0 || heads <= 0 || n_tiles < 0) return 0;
+    const size_t bwd = (size_t)(3 * m * heads + 64) * sizeof(float);
+    const size_t fwd = attn_mfma_workspace_bytes(n_tiles, heads, dh);
+    return bwd > fwd ? bwd : fwd;
 }
 
 int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk, int32_t ldv,
@@ -335,7 +253,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
     if (bad_common(q, k, v, tok, win_start, win_count, m, n_windows, heads, dh, tau, workspace) || !out || !dout ||
         !lse || !dq || !dk || !dv || !dtau)
         return SEG3D_EINVAL;
-    if (workspace_bytes < seg3d_window_attn_workspace_bytes(m, heads)) return SEG3D_EWORKSPACE;
+    if (workspace_bytes < (size_t)(3 * m * heads + 64) * sizeof(float)) return SEG3D_EWORKSPACE;
     AttnArgs a{q, k, v, ldq, ldk, ldv, tok, win_start, win_count, n_windows, heads, m, tau, tau_min};
     hipStream_t st = as_stream(stream);
     float* ws = static_cast<float*>(workspace);

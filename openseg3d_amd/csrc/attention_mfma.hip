@@ -1,0 +1,337 @@
+// a19-a21 forward on the matrix cores: ragged sparse-window cosine attention with split-bf16 MFMA.
+// Reference: flat2window -> CosineMultiheadAttention -> window2flat (swformer_utils.py:34-85,
+// point_transformer_layer.py:233-258, cosine_msa.py:115-177) -- padded [W,T,C] tensors, -inf masks and a
+// materialised (W*H, T, T) score tensor per encoder layer.
+//
+// Two launches per layer, no padding beyond 32-token tiles, no score tensor, no LDS in the core:
+//  1. attn_prepare_fwd: one workgroup per 32-token tile of a window.  Gathers the q/k/v rows of the tile
+//     (coalesced whole rows), L2-normalises q and k per head, folds log2(e)/max(tau, tau_min) into q, splits
+//     every value into bf16 hi + lo and writes
+//        Qp, Kp : [padded position][head][DHS]   (row-major; an MFMA A/B fragment = one 16-B load)
+//        Vt     : [head][d][padded position]     (transposed, positions permuted inside a tile so that the
+//                                                 score accumulator of the QK^T MFMAs is the B operand of PV)
+//  2. attn_core_fwd: one wave per (window, 16-query group, head).  Per 32-key tile: S^T = K.Q^T as
+//     2 x ksteps x 3 v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi), online softmax in registers (the 8
+//     scores a lane holds all belong to its own query column; row max/sum = 2 shuffles), P split to bf16
+//     hi/lo in place, O^T += V^T.P as d-blocks x 3 MFMAs.  Results go straight to flat voxel order.
+// Work items (tiles, query groups) come from seg3d_window_partition, so no thread ever sees an empty window.
+//
+// Algorithmic FLOPs: 4*C*sum_w n_w^2 per layer; executed MFMA FLOPs are 3x that (split) plus
+// tile padding.  Error: ~2^-16 relative per product (same budget as the sparse convs).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kNormEps = 1e-12f;  // F.normalize eps, cosine_msa.py:152-153
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+__device__ __forceinline__ void split1(float v, __bf16* hi, __bf16* lo) {
+    const __bf16 h = (__bf16)v;
+    *hi = h;
+    *lo = (__bf16)(v - (float)h);
+}
+
+// slot of tile-local token r in the transposed arrays: key kappa(g, j) = (j < 4 ? 4g + j : 16 + 4g + j - 4)
+// lives at slot 8g + j, so a lane's 8 score registers [u=0: r 0..3, u=1: r 0..3] line up with one 16-B load.
+__device__ __forceinline__ int perm_slot(int r) {
+    return r < 16 ? (r >> 2) * 8 + (r & 3) : ((r - 16) >> 2) * 8 + 4 + ((r - 16) & 3);
+}
+
+template <int DH>
+struct Geo {
+    static constexpr int DHS = (DH + 7) / 8 * 8;    // stored channels per head (multiple of 8)
+    static constexpr int KS = (DHS + 31) / 32;      // MFMA k-steps over the head dimension
+    static constexpr int NB = (DH + 15) / 16;       // 16-row d-blocks of the output
+};
+
+// ------------------------------------------------------------------ prepare
+template <int DH>
+__global__ __launch_bounds__(256) void attn_prepare_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, int ldq, int ldk, int ldv,
+                                                        const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
+                                                        const int32_t* __restrict__ win_count,
+                                                        const int32_t* __restrict__ win_tile0, const int2* __restrict__ tile_item,
+                                                        int heads, int64_t mpad, const float* __restrict__ tau, float tau_min,
+                                                        __bf16* __restrict__ qp, __bf16* __restrict__ kp, __bf16* __restrict__ vt) {
+    constexpr int DHS = Geo<DH>::DHS;
+    extern __shared__ float smem[];
+    const int c = heads * DH, cp = c + 1;
+    float* buf = smem;                      // [32][cp]
+    float* rn = smem + 32 * cp;             // [32][heads]
+    int32_t* trow = reinterpret_cast<int32_t*>(rn + 32 * heads);  // [32] token row or -1
+
+    const int2 item = tile_item[blockIdx.x];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int64_t pos0 = ((int64_t)win_tile0[item.x] + item.y) * 32;
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        const int i = item.y * 32 + tid;
+        trow[tid] = i < n ? tok[start + i] : -1;
+    }
+    const float qscale = kLog2e / fmaxf(tau[0], tau_min);
+    __syncthreads();
+
+    for (int which = 0; which < 3; ++which) {
+        const float* src = which == 0 ? q : which == 1 ? k : v;
+        const int ld = which == 0 ? ldq : which == 1 ? ldk : ldv;
+        for (int e = tid; e < 32 * c; e += 256) {
+            const int row = e / c, col = e - row * c;
+            const int t = trow[row];
+            buf[row * cp + col] = t >= 0 ? src[(int64_t)t * ld + col] : 0.f;
+        }
+        __syncthreads();
+        if (which < 2) {
+            for (int e = tid; e < 32 * heads; e += 256) {
+                const int row = e / heads, h = e - row * heads;
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) {
+                    const float x = buf[row * cp + h * DH + d];
+                    s = fmaf(x, x, s);
+                }
+                rn[e] = (which == 0 ? qscale : 1.0f) / fmaxf(sqrtf(s), kNormEps);
+            }
+            __syncthreads();
+            __bf16* dst = which == 0 ? qp : kp;
+            const int64_t half = mpad * heads * DHS;  // hi block then lo block
+            for (int e = tid; e < 32 * heads * DHS; e += 256) {
+                const int ds = e % DHS, h = (e / DHS) % heads, row = e / (DHS * heads);
+                const float x = ds < DH ? buf[row * cp + h * DH + ds] * rn[row * heads + h] : 0.f;
+                __bf16 hi, lo;
+                split1(x, &hi, &lo);
+                const int64_t o = ((pos0 + row) * heads + h) * DHS + ds;
+                dst[o] = hi;
+                dst[half + o] = lo;
+            }
+        } else {
+            const int64_t half = (int64_t)heads * DH * mpad;
+            for (int e = tid; e < 32 * c; e += 256) {
+                const int row = e & 31, ch = e >> 5;  // ch = h*DH + d
+                __bf16 hi, lo;
+                split1(buf[row * cp + ch], &hi, &lo);
+                const int64_t o = (int64_t)ch * mpad + pos0 + perm_slot(row);
+                vt[o] = hi;
+                vt[half + o] = lo;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ core
+template <int DH>
+__global__ __launch_bounds__(256) void attn_core_fwd(const __bf16* __restrict__ qp, const __bf16* __restrict__ kp,
+                                                     const __bf16* __restrict__ vt, const int32_t* __restrict__ tok,
+                                                     const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
+                                                     const int32_t* __restrict__ win_tile0, const int2* __restrict__ qg_item,
+                                                     int n_items, int heads, int64_t mpad, float* __restrict__ out,
+                                                     float* __restrict__ lse) {
+    constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = blockIdx.x * 4 + wave;
+    if (it >= n_items) return;  // wave-uniform
+    const int h = blockIdx.y;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int2 item = qg_item[it];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int64_t pos0 = (int64_t)win_tile0[item.x] * 32;
+    const int n_tiles = (n + 31) >> 5;
+    const int64_t qk_half = mpad * heads * DHS;
+    const int64_t vt_half = (int64_t)heads * DH * mpad;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // Q fragments of this wave's 16 queries: B operand, lane (query c16, channels 32s + 8g .. +7)
+    const int qi = item.y * 16 + c16;
+    bf16x8 q_hi[KS], q_lo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 a = zero4, b = zero4;
+        if (32 * s + 8 * g < DHS) {
+            const int64_t o = ((pos0 + qi) * heads + h) * DHS + 32 * s + 8 * g;
+            a = *reinterpret_cast<const u32x4*>(qp + o);
+            b = *reinterpret_cast<const u32x4*>(qp + qk_half + o);
+        }
+        q_hi[s] = __builtin_bit_cast(bf16x8, a);
+        q_lo[s] = __builtin_bit_cast(bf16x8, b);
+    }
+
+    f32x4 o_acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) o_acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int t = 0; t < n_tiles; ++t) {
+        // ---- S^T tile: two 16-key sub-tiles
+        f32x4 s_acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            s_acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int64_t krow = pos0 + t * 32 + u * 16 + c16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                u32x4 a = zero4, b = zero4;
+                if (32 * s + 8 * g < DHS) {
+                    const int64_t o = (krow * heads + h) * DHS + 32 * s + 8 * g;
+                    a = *reinterpret_cast<const u32x4*>(kp + o);
+                    b = *reinterpret_cast<const u32x4*>(kp + qk_half + o);
+                }
+                const bf16x8 k_hi = __builtin_bit_cast(bf16x8, a), k_lo = __builtin_bit_cast(bf16x8, b);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_lo, q_hi[s], s_acc[u], 0, 0, 0);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_lo[s], s_acc[u], 0, 0, 0);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_hi[s], s_acc[u], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over this lane's query column (keys: 4g + r in each sub-tile)
+        float sc[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 32 + u * 16 + g * 4 + r;
+                const float x = key < n ? s_acc[u][r] : -INFINITY;
+                sc[u * 4 + r] = x;
+                tmax = fmaxf(tmax, x);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, SEG3D_WAVE));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, SEG3D_WAVE));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_new);
+            psum += sc[i];
+        }
+        psum += __shfl_xor(psum, 16, SEG3D_WAVE);
+        psum += __shfl_xor(psum, 32, SEG3D_WAVE);
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+        // ---- P fragment (B operand of PV): hi/lo split in place
+        u32x4 ph, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = pack_bf16(sc[2 * i], sc[2 * i + 1]);
+            const float h0 = __builtin_bit_cast(float, w << 16);
+            const float h1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+            ph[i] = w;
+            pl[i] = pack_bf16(sc[2 * i] - h0, sc[2 * i + 1] - h1);
+        }
+        const bf16x8 p_hi = __builtin_bit_cast(bf16x8, ph), p_lo = __builtin_bit_cast(bf16x8, pl);
+        // ---- O^T += V^T . P
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            u32x4 a = zero4, c = zero4;
+            const int d = 16 * b + c16;
+            if (d < DH) {
+                const int64_t o = ((int64_t)h * DH + d) * mpad + pos0 + t * 32 + 8 * g;
+                a = *reinterpret_cast<const u32x4*>(vt + o);
+                c = *reinterpret_cast<const u32x4*>(vt + vt_half + o);
+            }
+            const bf16x8 v_hi = __builtin_bit_cast(bf16x8, a), v_lo = __builtin_bit_cast(bf16x8, c);
+            f32x4 acc = o_acc[b] * alpha;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_lo, p_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_hi, acc, 0, 0, 0);
+            o_acc[b] = acc;
+        }
+    }
+
+    // ---- epilogue: O^T[d = 16b + 4g + r][query c16] / l  ->  out[token][h*DH + d]
+    if (qi < n) {
+        const int32_t token = tok[start + qi];
+        const float inv = 1.0f / l_run;
+        float* op = out + (int64_t)token * (heads * DH) + h * DH;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * b + 4 * g + r;
+                if (d < DH) op[d] = o_acc[b][r] * inv;
+            }
+        if (lse && g == 0) lse[(int64_t)token * heads + h] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
+    }
+}
+
+template <int DH>
+size_t prepared_bytes(int64_t mpad, int heads) {
+    const size_t qk = (size_t)mpad * heads * Geo<DH>::DHS * 2 * sizeof(__bf16);  // hi + lo
+    const size_t vt = (size_t)heads * DH * mpad * 2 * sizeof(__bf16);
+    return 2 * align_up(qk, 256) + align_up(vt, 256);
+}
+
+template <int DH>
+int run_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+            const int32_t* win_start, const int32_t* win_count, const int32_t* win_tile0, const int2* tile_item,
+            int n_tiles, const int2* qg_item, int n_qg, int heads, const float* tau, float tau_min, float* out,
+            float* lse, void* workspace, hipStream_t st) {
+    const int64_t mpad = (int64_t)n_tiles * 32;
+    const size_t qk = align_up((size_t)mpad * heads * Geo<DH>::DHS * 2 * sizeof(__bf16), 256);
+    char* base = static_cast<char*>(workspace);
+    __bf16* qp = reinterpret_cast<__bf16*>(base);
+    __bf16* kp = reinterpret_cast<__bf16*>(base + qk);
+    __bf16* vt = reinterpret_cast<__bf16*>(base + 2 * qk);
+    const int c = heads * DH;
+    const size_t smem = (size_t)(32 * (c + 1) + 32 * heads) * sizeof(float) + 32 * sizeof(int32_t);
+    hipLaunchKernelGGL(attn_prepare_fwd<DH>, dim3((unsigned)n_tiles), dim3(256), smem, st, q, k, v, ldq, ldk, ldv, tok,
+                       win_start, win_count, win_tile0, tile_item, heads, mpad, tau, tau_min, qp, kp, vt);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_core_fwd<DH>, dim3((unsigned)((n_qg + 3) / 4), (unsigned)heads), dim3(256), 0, st, qp, kp, vt,
+                       tok, win_start, win_count, win_tile0, qg_item, n_qg, heads, mpad, out, lse);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+}  // namespace
+
+size_t attn_mfma_workspace_bytes(int n_tiles, int heads, int dh) {
+    const int64_t mpad = (int64_t)n_tiles * 32;
+    switch (dh) {
+        case 6: return prepared_bytes<6>(mpad, heads);
+        case 12: return prepared_bytes<12>(mpad, heads);
+        case 24: return prepared_bytes<24>(mpad, heads);
+        case 48: return prepared_bytes<48>(mpad, heads);
+        default: return 0;
+    }
+}
+
+extern "C" int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk, int32_t ldv,
+                                     const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
+                                     const int32_t* win_tile0, const int32_t* tile_item, int32_t n_tiles,
+                                     const int32_t* qg_item, int32_t n_qgroups, int64_t m, int32_t n_windows,
+                                     int32_t heads, int32_t dh, const float* tau, float tau_min, float* out, float* lse,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) return SEG3D_OK;
+    if (!q || !k || !v || !tok || !win_start || !win_count || !win_tile0 || !tile_item || !qg_item || m < 0 ||
+        n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !out || !workspace)
+        return SEG3D_EINVAL;
+    const size_t need = attn_mfma_workspace_bytes(n_tiles, heads, dh);
+    if (need == 0) return SEG3D_EINVAL;
+    if (workspace_bytes < need) return SEG3D_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int2* ti = reinterpret_cast<const int2*>(tile_item);
+    const int2* qi = reinterpret_cast<const int2*>(qg_item);
+    switch (dh) {
+        case 6: return run_fwd<6>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, win_tile0, ti, n_tiles, qi, n_qgroups,
+                                  heads, tau, tau_min, out, lse, workspace, st);
+        case 12: return run_fwd<12>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, win_tile0, ti, n_tiles, qi,
+                                    n_qgroups, heads, tau, tau_min, out, lse, workspace, st);
+        case 24: return run_fwd<24>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, win_tile0, ti, n_tiles, qi,
+                                    n_qgroups, heads, tau, tau_min, out, lse, workspace, st);
+        case 48: return run_fwd<48>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, win_tile0, ti, n_tiles, qi,
+                                    n_qgroups, heads, tau, tau_min, out, lse, workspace, st);
+        default: return SEG3D_EINVAL;
+    }
+}

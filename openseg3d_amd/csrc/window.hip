@@ -90,20 +90,40 @@ __global__ __launch_bounds__(kThreads) void win_per_voxel(const int32_t* __restr
     if (s < 0) atomicAdd(&counts[1], 1);
 }
 
-__global__ __launch_bounds__(kThreads) void win_compact(const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs,
-                                                        const uint4* __restrict__ lvl_prefix, int64_t n_canvas,
-                                                        int32_t* __restrict__ win_start, int32_t* __restrict__ win_count,
-                                                        int32_t* __restrict__ counts) {
+// per canvas entry: (non-empty, 32-token tiles, 16-token query groups, 0) -- scanned to give every window its
+// compact index, its first tile in the 32-padded token space and its first attention work item
+__global__ __launch_bounds__(kThreads) void win_geom_flags(const uint32_t* __restrict__ count, int64_t n_canvas,
+                                                           uint4* __restrict__ flags) {
     const int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (w >= n_canvas) return;
     const uint32_t n = count[w];
-    const uint4 p = lvl_prefix[w];
-    const uint32_t cw = p.x + p.y + p.z + p.w;  // non-empty windows with a smaller id
+    flags[w] = make_uint4(n ? 1u : 0u, (n + 31u) >> 5, (n + 15u) >> 4, 0u);
+}
+
+__global__ __launch_bounds__(kThreads) void win_compact(const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs,
+                                                        const uint4* __restrict__ geom_prefix, int64_t n_canvas,
+                                                        int32_t* __restrict__ win_start, int32_t* __restrict__ win_count,
+                                                        int32_t* __restrict__ win_tile0, int2* __restrict__ tile_item,
+                                                        int2* __restrict__ qg_item, int32_t* __restrict__ counts) {
+    const int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (w >= n_canvas) return;
+    const uint32_t n = count[w];
+    const uint4 p = geom_prefix[w];
+    const uint32_t cw = p.x;  // non-empty windows with a smaller id
     if (n) {
         win_start[cw] = (int32_t)offs[w];
         win_count[cw] = (int32_t)n;
+        if (win_tile0) win_tile0[cw] = (int32_t)p.y;
+        if (tile_item)
+            for (uint32_t t = 0; t < ((n + 31u) >> 5); ++t) tile_item[p.y + t] = make_int2((int)cw, (int)t);
+        if (qg_item)
+            for (uint32_t q = 0; q < ((n + 15u) >> 4); ++q) qg_item[p.z + q] = make_int2((int)cw, (int)q);
     }
-    if (w == n_canvas - 1) counts[0] = (int32_t)(cw + (n ? 1u : 0u));
+    if (w == n_canvas - 1) {
+        counts[0] = (int32_t)(cw + (n ? 1u : 0u));
+        counts[2] = (int32_t)(p.y + ((n + 31u) >> 5));
+        counts[3] = (int32_t)(p.z + ((n + 15u) >> 4));
+    }
 }
 
 // a17 -- one thread per (voxel, output channel)
@@ -138,6 +158,7 @@ size_t seg3d_window_partition_workspace_bytes(int64_t m, int32_t batch_size, con
     WsCarver c(nullptr);
     c.take<char>(seg3d_group_index_workspace_bytes(m, (int64_t)nc));
     c.take<uint4>(nc + 1);
+    c.take<uint4>(nc + 1);
     c.take<uint4>(scan_tmp_count((int64_t)nc));
     c.take<int32_t>((size_t)m + 1);  // win ids when the caller passes NULL
     c.take<int32_t>((size_t)m + 1);  // ranks when the caller passes NULL
@@ -148,7 +169,8 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
                            const int32_t* nwin_xyz, const int32_t* shift_xyz, int32_t n_levels, const int32_t* level_lo,
                            const int32_t* level_hi, const int32_t* level_cap, int32_t* win_id, int32_t* in_win,
                            int32_t* rank, int32_t* level, int32_t* slot, int32_t* tok, int32_t* win_start,
-                           int32_t* win_count, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
+                           int32_t* win_count, int32_t* win_tile0, int32_t* tile_item, int32_t* qg_item,
+                           int32_t* counts, void* workspace, size_t workspace_bytes, void* stream) {
     if (m < 0 || batch_size <= 0 || !win_xyz || !nwin_xyz || !shift_xyz || n_levels < 1 || n_levels > kMaxLevels ||
         !level_lo || !level_hi || !level_cap || !tok || !win_start || !win_count || !counts || !workspace ||
         (m > 0 && !coords))
@@ -163,6 +185,7 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
     WsCarver c(workspace);
     void* grp_ws = c.take<char>(seg3d_group_index_workspace_bytes(m, (int64_t)nc));
     uint4* lvl = c.take<uint4>(nc + 1);
+    uint4* geom = c.take<uint4>(nc + 1);
     uint4* lvl_tmp = c.take<uint4>(scan_tmp_count((int64_t)nc));
     int32_t* wid_ws = c.take<int32_t>((size_t)m + 1);
     int32_t* rank_ws = c.take<int32_t>((size_t)m + 1);
@@ -182,7 +205,7 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
         lv.hi[j] = j < n_levels ? level_hi[j] : 0;
         lv.cap[j] = j < n_levels ? level_cap[j] : 0;
     }
-    if (hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st) != hipSuccess) return SEG3D_ELAUNCH;
+    if (hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st) != hipSuccess) return SEG3D_ELAUNCH;
     if (m == 0) return SEG3D_OK;
 
     const unsigned nbv = (unsigned)ceil_div64(m, kThreads), nbc = (unsigned)ceil_div64((int64_t)nc, kThreads);
@@ -191,6 +214,7 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
     uint32_t *count = nullptr, *offs = nullptr;
     int rc = group_index_launch(win_id, m, (int64_t)nc, rank, tok, nullptr, grp_ws, st, &count, &offs);
     if (rc != SEG3D_OK) return rc;
+    // batching levels / flat2window slots (the reference's intermediates) also detect dropped voxels
     hipLaunchKernelGGL(win_level_flags, dim3(nbc), dim3(kThreads), 0, st, count, (int64_t)nc, lv, lvl);
     SEG3D_CHECK_LAUNCH();
     rc = scan_exclusive_u32x4(lvl, lvl, (int64_t)nc, nullptr, lvl_tmp, st);
@@ -198,8 +222,14 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
     hipLaunchKernelGGL(win_per_voxel, dim3(nbv), dim3(kThreads), 0, st, win_id, rank, m, count, lvl, lv, level, slot,
                        counts);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(win_compact, dim3(nbc), dim3(kThreads), 0, st, count, offs, lvl, (int64_t)nc, win_start,
-                       win_count, counts);
+    // CSR of non-empty windows + 32-padded tile geometry + attention work items
+    hipLaunchKernelGGL(win_geom_flags, dim3(nbc), dim3(kThreads), 0, st, count, (int64_t)nc, geom);
+    SEG3D_CHECK_LAUNCH();
+    rc = scan_exclusive_u32x4(geom, geom, (int64_t)nc, nullptr, lvl_tmp, st);
+    if (rc != SEG3D_OK) return rc;
+    hipLaunchKernelGGL(win_compact, dim3(nbc), dim3(kThreads), 0, st, count, offs, geom, (int64_t)nc, win_start,
+                       win_count, win_tile0, reinterpret_cast<int2*>(tile_item), reinterpret_cast<int2*>(qg_item),
+                       counts);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

@@ -251,8 +251,8 @@ def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None):
 # ------------------------------------------------------------------------------------------ a13-a18 windows
 class WindowIndex:
     """Outputs of seg3d_window_partition for one (stage, shift)."""
-    __slots__ = ("win_id", "in_win", "rank", "level", "slot", "tok", "win_start", "win_count", "counts",
-                 "n_windows", "n_dropped", "m")
+    __slots__ = ("win_id", "in_win", "rank", "level", "slot", "tok", "win_start", "win_count", "win_tile0",
+                 "tile_item", "qg_item", "counts", "n_windows", "n_dropped", "n_tiles", "n_qgroups", "m")
 
 
 def window_partition(coords, batch_size, window_shape, nwin_xyz, shift_xyz, levels, want_debug=False):
@@ -274,17 +274,19 @@ def window_partition(coords, batch_size, window_shape, nwin_xyz, shift_xyz, leve
     wi.tok = torch.empty((max(m, 1),), **i32)
     wi.win_start = torch.empty((cap,), **i32)
     wi.win_count = torch.empty((cap,), **i32)
-    wi.counts = torch.zeros((2,), **i32)
+    wi.win_tile0 = torch.empty((cap,), **i32)
+    wi.tile_item = torch.empty((m // 32 + cap + 1, 2), **i32)
+    wi.qg_item = torch.empty((m // 16 + cap + 1, 2), **i32)
+    wi.counts = torch.zeros((4,), **i32)
     nl = len(levels)
     arr = ctypes.c_int32 * nl
     lo, hi, capt = arr(*[int(l[0]) for l in levels]), arr(*[int(l[1]) for l in levels]), arr(*[int(l[2]) for l in levels])
     ws = _workspace(_lib.query("seg3d_window_partition_workspace_bytes", m, int(batch_size), _i3(nwin_xyz)), dev)
     _lib.call("seg3d_window_partition", _ptr(coords), m, int(batch_size), _i3(window_shape), _i3(nwin_xyz),
               _i3(shift_xyz), nl, lo, hi, capt, _ptr(wi.win_id), _ptr(wi.in_win), _ptr(wi.rank), _ptr(wi.level),
-              _ptr(wi.slot), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.counts), _ptr(ws),
-              ws.numel(), _stream())
-    wi.n_windows = None
-    wi.n_dropped = None
+              _ptr(wi.slot), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0),
+              _ptr(wi.tile_item), _ptr(wi.qg_item), _ptr(wi.counts), _ptr(ws), ws.numel(), _stream())
+    wi.n_windows = wi.n_dropped = wi.n_tiles = wi.n_qgroups = None  # filled by the caller's one sync
     return wi
 
 
@@ -304,10 +306,11 @@ class _WindowAttnFn(torch.autograd.Function):
         dev = v.device
         out = torch.empty((m, c), dtype=torch.float32, device=dev)
         lse = torch.empty((m, heads), dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, heads), dev)
+        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, dh), dev)
         tau_f = tau.reshape(-1)
         _lib.call("seg3d_window_attn_fwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
-                  _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), m, int(wi.n_windows), heads, dh,
+                  _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0), _ptr(wi.tile_item),
+                  int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m, int(wi.n_windows), heads, dh,
                   _ptr(tau_f), float(tau_min), _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
         ctx.save_for_backward(q, k, v, tau, out, lse)
         ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
@@ -322,7 +325,7 @@ class _WindowAttnFn(torch.autograd.Function):
         dout = _f32c(dout)
         dq, dk, dv = (torch.empty((m, c), dtype=torch.float32, device=dev) for _ in range(3))
         dtau = torch.zeros((1,), dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, heads), dev)
+        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, c // heads), dev)
         _lib.call("seg3d_window_attn_bwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
                   _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), m,
                   int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), _ptr(dq), _ptr(dk),

@@ -88,8 +88,8 @@ class SparseWindowPartitionLayer(nn.Module):
             index.append(wi)
             pos.append(ops.pos_embed(wi.in_win, win, self.inv_freq(feat_dim, coords.device), feat_dim))
         counts = torch.stack([wi.counts for wi in index]).tolist()  # the stage's one host sync
-        for wi, (n_win, n_drop) in zip(index, counts):
-            wi.n_windows, wi.n_dropped = int(n_win), int(n_drop)
+        for wi, (n_win, n_drop, n_tiles, n_qg) in zip(index, counts):
+            wi.n_windows, wi.n_dropped, wi.n_tiles, wi.n_qgroups = int(n_win), int(n_drop), int(n_tiles), int(n_qg)
             if n_drop:
                 raise RuntimeError(
                     f"{n_drop} voxels exceed max_tokens of their batching level: voxel dropping is "
