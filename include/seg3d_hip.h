@@ -205,7 +205,9 @@ int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_
 int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
                           int32_t ldv, const float* out, const float* dout, const float* lse,
                           const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
-                          int64_t m, int32_t n_windows, int32_t heads, int32_t dh, const float* tau,
+                          const int32_t* win_tile0, const int32_t* tile_item, int32_t n_tiles,
+                          const int32_t* qg_item, int32_t n_qgroups, int64_t m, int32_t n_windows,
+                          int32_t heads, int32_t dh, const float* tau,
                           float tau_min, float* dq, float* dk, float* dv, int32_t lddq, int32_t lddk,
                           int32_t lddv, float* dtau, void* workspace, size_t workspace_bytes,
                           void* stream);

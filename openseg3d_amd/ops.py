@@ -327,7 +327,8 @@ class _WindowAttnFn(torch.autograd.Function):
         dtau = torch.zeros((1,), dtype=torch.float32, device=dev)
         ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, c // heads), dev)
         _lib.call("seg3d_window_attn_bwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
-                  _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), m,
+                  _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count),
+                  _ptr(wi.win_tile0), _ptr(wi.tile_item), int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m,
                   int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), _ptr(dq), _ptr(dk),
                   _ptr(dv), c, c, c, _ptr(dtau), _ptr(ws), ws.numel(), _stream())
         return dq, dk, dv, dtau.reshape(tau.shape), None, None, None
