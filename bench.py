@@ -5,9 +5,10 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input per GPU: GPU voxelisation of
 a resident Waymo-shaped scene (~180 k float32 points, 0.1 m voxels, grid 1440x1440x64, i.e.
-configs/waymo_one_sweep.yaml = BASELINE.json configs[1]) followed by Segformer forward
-(mode fwd, eval) or forward + loss + backward + optimizer step (mode fwdbwd, train; gradients
-all-reduced over RCCL when N > 1).  Scenes shard data-parallel: every rank processes its own scenes,
+configs/waymo_one_sweep.yaml = BASELINE.json configs[1]) followed by Segformer forward + loss +
+backward + SGD step (default mode fwdbwd = the metric "points/sec fwd+bwd"; gradients all-reduced
+over RCCL when N > 1).  The forward-only eval rate of the same scenes is timed in the same run and
+reported as `fwd_only` (mode fwd makes it the headline instead).  Scenes shard data-parallel: every rank processes its own scenes,
 `value` = points processed by all ranks / max-over-ranks wall time ("scaling": "weak").
 
 Prints ONE JSON line on rank 0 with the contract fields plus
@@ -34,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["fwd", "fwdbwd"], default="fwd")
+    ap.add_argument("--mode", choices=["fwd", "fwdbwd"], default="fwdbwd")
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
     ap.add_argument("--batch", type=int, default=1, help="scenes per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,7 +135,7 @@ def main():
     rank, world, local = setup_dist(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    from openseg3d_amd import batch as B, config, scene, segformer
+    from openseg3d_amd import batch as B, config, dist as D, scene, segformer
     dev = torch.device("cuda", local)
     cfg = config.default_cfg()  # == configs/waymo_one_sweep.yaml for every key the model path reads
     ds = config.DatasetSpec(cfg)
@@ -150,26 +151,24 @@ def main():
     pts_per_step = [int(r.shape[0]) for r in resident]
 
     train = args.mode == "fwdbwd"
-    if train:
-        model.train()
-        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)  # configs/waymo_one_sweep.yaml
-        net = model
-        if world > 1:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
-        labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
-    else:
-        model.eval()
-        net = model
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)  # configs/waymo_one_sweep.yaml
+    net = model
+    if train and world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
+    labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
+    ce = torch.nn.functional.cross_entropy
 
-    def step(i):
+    def fwd_step(i):
         j = i % len(resident)
         b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range)
-        if not train:
-            with torch.no_grad():
-                return net(b)
+        with torch.no_grad():
+            return model(b)
+
+    def train_step(i):
+        j = i % len(resident)
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range)
         opt.zero_grad(set_to_none=True)
         res = net(b)
-        ce = torch.nn.functional.cross_entropy
         vox_lab = labels[j][:1].expand(res["voxel_out"].shape[0])  # constant voxel labels: loss plumbing only
         aux_lab = labels[j][:1].expand(res["aux_voxel_out"].shape[0])
         loss = ce(res["point_out"], labels[j]) + ce(res["voxel_out"], vox_lab) + 0.4 * ce(res["aux_voxel_out"], aux_lab)
@@ -177,24 +176,25 @@ def main():
         opt.step()
         return res
 
-    for i in range(args.warmup):
-        step(i)
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier(world)
-    dt = time.perf_counter() - t0
-    n_pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
+    def timed(step_fn):
+        for i in range(args.warmup):
+            step_fn(i)
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_fn(args.warmup + i)
+        barrier(world)
+        sec = time.perf_counter() - t0
+        pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
+        return D.aggregate_throughput(sec, pts, dev)
 
-    stats = torch.tensor([dt, float(n_pts)], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        psum = stats[1:].clone()
-        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
-        dt, n_pts = float(tmax.item()), float(psum.item())
+    if train:
+        model.train()
+        dt, n_pts = timed(train_step)
+    model.eval()
+    dt_f, n_pts_f = timed(fwd_step)  # forward-only eval (BASELINE configs[1] as literally worded)
+    if not train:
+        dt, n_pts = dt_f, n_pts_f
 
     out = None
     if rank == 0:
@@ -211,6 +211,8 @@ def main():
                                    f"{'forward-only eval' if not train else 'fwd+loss+bwd+SGD step'}",
                        "mode": args.mode, "scenes_per_step_per_gpu": args.batch,
                        "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}"},
+            "fwd_only": {"value": round(n_pts_f / dt_f, 1), "unit": "points/s",
+                         "ms_per_step": round(dt_f / args.steps * 1e3, 3)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -26,13 +26,14 @@ struct BwdWs {
     __bf16 *qp, *kp, *vp, *gp;  // row-major  [mpad][heads][DHS], hi block then lo block
     __bf16 *qt, *kt, *gt;       // transposed [heads][DH][mpad],  hi block then lo block
     float *lp, *dp;             // [mpad][heads]: log2-domain LSE, delta
+    float* tau_part;            // [256] partial tau gradients (one address would serialise ~1e5 atomics)
     static size_t row_bytes(int64_t mpad, int heads) {
         return align_up((size_t)mpad * heads * Geo<DH>::DHS * 2 * sizeof(__bf16), 256);
     }
     static size_t tr_bytes(int64_t mpad, int heads) { return align_up((size_t)heads * DH * mpad * 2 * sizeof(__bf16), 256); }
     static size_t f_bytes(int64_t mpad, int heads) { return align_up((size_t)mpad * heads * sizeof(float), 256); }
     static size_t total(int64_t mpad, int heads) {
-        return 4 * row_bytes(mpad, heads) + 3 * tr_bytes(mpad, heads) + 2 * f_bytes(mpad, heads);
+        return 4 * row_bytes(mpad, heads) + 3 * tr_bytes(mpad, heads) + 2 * f_bytes(mpad, heads) + 1024;
     }
     BwdWs(void* base, int64_t mpad, int heads) {
         char* p = static_cast<char*>(base);
@@ -46,6 +47,7 @@ struct BwdWs {
         gt = reinterpret_cast<__bf16*>(take(tr_bytes(mpad, heads)));
         lp = reinterpret_cast<float*>(take(f_bytes(mpad, heads)));
         dp = reinterpret_cast<float*>(take(f_bytes(mpad, heads)));
+        tau_part = reinterpret_cast<float*>(take(1024));
     }
 };
 
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __r
                                                   const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
                                                   const int2* __restrict__ qg_item, int n_items, int heads, int64_t mpad,
                                                   const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
-                                                  int lddq, float* __restrict__ dtau) {
+                                                  int lddq) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int it = blockIdx.x * 4 + wave;
@@ -271,7 +273,16 @@ __global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __r
     }
     // d/dtau: s_nat = s2 * ln2 = c / tau  ->  dL/dtau = -sum(ds * s_nat) / tau   (zero while tau is clamped)
     for (int off = 32; off > 0; off >>= 1) tau_acc += __shfl_xor(tau_acc, off, SEG3D_WAVE);
-    if (lane == 0 && tau[0] > tau_min && tau_acc != 0.f) atomicAdd(dtau, -tau_acc * kLn2 / tau_c);
+    if (lane == 0 && tau[0] > tau_min && tau_acc != 0.f) atomicAdd(&ws.tau_part[it & 255], -tau_acc * kLn2 / tau_c);
+}
+
+__global__ __launch_bounds__(256) void tau_reduce(const float* __restrict__ part, float* __restrict__ dtau) {
+    float v = part[threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, SEG3D_WAVE);
+    __shared__ float w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) dtau[0] += w[0] + w[1] + w[2] + w[3];
 }
 
 // ------------------------------------------------------------------ pass B: dk, dv
@@ -385,8 +396,11 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
                        lse, tok, win_start, win_count, win_tile0, tile_item, heads, mpad, tau, tau_min, ws);
     SEG3D_CHECK_LAUNCH();
     dim3 grid((unsigned)((n_qg + 3) / 4), (unsigned)heads);
+    if (hipMemsetAsync(ws.tau_part, 0, 1024, st) != hipSuccess) return SEG3D_ELAUNCH;
     hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, qg_item,
-                       n_qg, heads, mpad, tau, tau_min, dq, lddq, dtau);
+                       n_qg, heads, mpad, tau, tau_min, dq, lddq);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(256), 0, st, ws.tau_part, dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_kv<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0, qg_item,
                        n_qg, heads, mpad, dk, lddk, dv, lddv);

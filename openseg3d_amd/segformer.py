@@ -166,9 +166,29 @@ class PointTransformer(nn.Module):
         return batch_dict
 
 
+class NarrowBatchNorm1d(nn.BatchNorm1d):
+    """BatchNorm1d for very narrow inputs (the 6/8 raw point channels, segformer.py:22).  Same parameters,
+    buffers and arithmetic as nn.BatchNorm1d; in training mode the batch statistics are taken with plain
+    column reductions, because torch's generic batch-norm backward kernel needs ~7 ms on a [175k, 6] tensor."""
+
+    def forward(self, x):
+        if not self.training or not self.track_running_stats:
+            return super().forward(x)
+        mean = x.mean(dim=0)
+        var = x.var(dim=0, unbiased=False)
+        with torch.no_grad():
+            n = x.shape[0]
+            self.num_batches_tracked += 1
+            mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            self.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            self.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+        y = (x - mean) * torch.rsqrt(var + self.eps)
+        return y * self.weight + self.bias if self.affine else y
+
+
 def _bn_mlp(dims, first_bn=None, last_plain=False):
     """[BN(d0)] + (Linear(no bias) + BN + ReLU)* [+ Linear(bias)] with the reference's Sequential numbering."""
-    mods = [nn.BatchNorm1d(first_bn)] if first_bn is not None else []
+    mods = [NarrowBatchNorm1d(first_bn)] if first_bn is not None else []
     n = len(dims) - 1
     for i in range(n):
         if last_plain and i == n - 1:
