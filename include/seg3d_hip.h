@@ -138,8 +138,15 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
                      int32_t cin, int32_t cout, float* y, void* stream);
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout);
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out,
-                       int64_t m_in, int32_t cin, int32_t cout, float* dw, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       int64_t m_in, int32_t cin, int32_t cout, int32_t flags /* bit2: split-bf16 */,
+                       float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* a6, a22  weight gradient of the dense per-point / per-voxel Linear layers (segformer.py:21-32,58-76,
+ * point_transformer_layer.py:260-276, cosine_msa.py:58-63,403):  dw[cout][cin] = dy^T . x  over m rows.
+ * Same split-bf16 tall-skinny kernel as the sparse wgrad (rows = MFMA K dimension); the forward and the
+ * input-gradient GEMMs stay on rocBLAS/hipBLASLt.  cin, cout multiples of 4. */
+int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /

@@ -17,6 +17,8 @@ size_t spconv_split_packed_bytes(int cin_op, int cout_op);
 int spconv_split_pack(const float* weight, int cin, int cout, int transpose, int flip, void* w_packed, hipStream_t st);
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
                      int cout, float* y, hipStream_t st);
+int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
+                       hipStream_t st);  // wgrad_split.hip
 
 namespace {
 
@@ -310,12 +312,13 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t, int32_t, int32_t) { return 256; }
 
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int64_t m_in, int32_t cin,
-                       int32_t cout, float* dw, void*, size_t, void* stream) {
+                       int32_t cout, int32_t flags, float* dw, void*, size_t, void* stream) {
     if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !dw) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(dw, 0, (size_t)27 * cin * cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
     if (m_out == 0) return SEG3D_OK;
     if (!x || !dy || !nbr) return SEG3D_EINVAL;
+    if (flags & 4) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, st);
     const int ja = pick_j(cin), jb = pick_j(cout);
     switch (ja) {
         case 4: return launch_wgrad_b<4>(jb, x, dy, nbr, m_out, cin, cout, dw, st);

@@ -237,7 +237,7 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, dtype=torch.float32)
             _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
-                      _ptr(dw), None, 0, _stream())
+                      _precision_flag(), _ptr(dw), None, 0, _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None, None, None
@@ -246,6 +246,42 @@ class _SparseConvFn(torch.autograd.Function):
 def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None):
     _need_gpu(x, weight, nbr)
     return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed)
+
+
+# ------------------------------------------------------------------------------------------ a6/a22 dense layers
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with torch GEMMs for y and dx; dW through the split-bf16 tall-skinny kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ weight
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            _lib.call("seg3d_linear_wgrad", _ptr(_f32c(x)), _ptr(dy), x.shape[0], weight.shape[1], weight.shape[0],
+                      _ptr(dw), _stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear for [rows, C] activations; in training the weight gradient runs in libseg3d_hip.so."""
+    usable = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 4 == 0
+              and weight.shape[1] % 4 == 0 and torch.is_grad_enabled() and weight.requires_grad
+              and CONV_PRECISION == "bf16x3")
+    if not usable:
+        return torch.nn.functional.linear(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------ a13-a18 windows

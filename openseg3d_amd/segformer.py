@@ -186,15 +186,22 @@ class NarrowBatchNorm1d(nn.BatchNorm1d):
         return y * self.weight + self.bias if self.affine else y
 
 
+class RowLinear(nn.Linear):
+    """nn.Linear on [rows, C] activations whose weight gradient runs in libseg3d_hip.so (ops.linear)."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
 def _bn_mlp(dims, first_bn=None, last_plain=False):
     """[BN(d0)] + (Linear(no bias) + BN + ReLU)* [+ Linear(bias)] with the reference's Sequential numbering."""
     mods = [NarrowBatchNorm1d(first_bn)] if first_bn is not None else []
     n = len(dims) - 1
     for i in range(n):
         if last_plain and i == n - 1:
-            mods.append(nn.Linear(dims[i], dims[i + 1]))
+            mods.append(RowLinear(dims[i], dims[i + 1]))
         else:
-            mods += [nn.Linear(dims[i], dims[i + 1], bias=False), nn.BatchNorm1d(dims[i + 1]), nn.ReLU(inplace=True)]
+            mods += [RowLinear(dims[i], dims[i + 1], bias=False), nn.BatchNorm1d(dims[i + 1]), nn.ReLU(inplace=True)]
     return nn.Sequential(*mods)
 
 

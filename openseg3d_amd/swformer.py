@@ -120,10 +120,10 @@ class CosineMultiheadAttention(nn.Module):
     def forward(self, x, pos, wi):
         """x [M, C] flat voxel features, pos [M, C]; q = k = (x + pos) W_qk, v = x W_v (cosine_msa.py:58-63)."""
         c = self.embed_dim
-        qk = F.linear(x + pos, self.in_proj_weight[: 2 * c], self.in_proj_bias[: 2 * c])
-        v = F.linear(x, self.in_proj_weight[2 * c:], self.in_proj_bias[2 * c:])
+        qk = ops.linear(x + pos, self.in_proj_weight[: 2 * c], self.in_proj_bias[: 2 * c])
+        v = ops.linear(x, self.in_proj_weight[2 * c:], self.in_proj_bias[2 * c:])
         o = ops.window_attention(qk[:, :c], qk[:, c:], v, self.tau, self.tau_min, self.num_heads, wi)
-        return self.out_proj(o)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
 class WindowAttention(nn.Module):
@@ -143,10 +143,10 @@ class MLP(nn.Module):
         self.drop = drop
 
     def forward(self, x):
-        x = F.gelu(self.fc1(x))
+        x = F.gelu(ops.linear(x, self.fc1.weight, self.fc1.bias))
         if self.drop and self.training:
             x = F.dropout(x, self.drop)
-        x = self.fc2(x)
+        x = ops.linear(x, self.fc2.weight, self.fc2.bias)
         if self.drop and self.training:
             x = F.dropout(x, self.drop)
         return x
