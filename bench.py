@@ -98,9 +98,19 @@ def conv_roofline(model, batch, dev):
                           "GBs": round(algo / ms / 1e6, 1)})
     n = max(len(records), 1)
     achieved = tot_bytes / tot_ms / 1e6 if tot_ms > 0 else 0.0
-    return {"bound": "hbm", "kernel": "spconv_fwd_kernel (all sparse-conv launches of one forward)",
+    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 correction +
+    # WRITE_SIZE, two separate rocprofv3 --pmc runs of this same workload); only quoted when the profiled
+    # workload is the one just run (same algorithmic bytes), otherwise null.
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            p = json.load(f)
+        if abs(p.get("algorithmic_bytes_per_launch", 0) - tot_bytes / n) <= 0.01 * tot_bytes / n:
+            traffic = p["traffic_bytes_per_launch"]
+    return {"bound": "hbm", "kernel": "spconv_split_kernel (all 20 sparse-conv launches of one forward)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(records),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches": len(records),
             "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
 
 
