@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
+ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
 
 
 def parse():
@@ -76,13 +77,42 @@ def conv_roofline(model, batch, dev):
         records.append((nbr, cin, cout, e0, e1))
         return y
 
+    attn_records = []
+    orig_attn = ops.window_attention
+
+    def timed_attn(q, k, v, tau, tau_min, heads, wi):  # noqa: E306
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o = orig_attn(q, k, v, tau, tau_min, heads, wi)
+        e1.record()
+        attn_records.append((wi, v.shape[1], e0, e1))
+        return o
+
     ops._conv_apply = timed
+    ops.window_attention = timed_attn
     try:
         with torch.no_grad():
             model(dict(batch))
         torch.cuda.synchronize()
     finally:
         ops._conv_apply = orig
+        ops.window_attention = orig_attn
+    # window attention (prepare + core kernels of one layer): algorithmic FLOPs 4*C*sum_w n_w^2
+    sq_cache, a_flop, a_ms = {}, 0.0, 0.0
+    for wi, c, e0, e1 in attn_records:
+        if id(wi) not in sq_cache:
+            cnt = wi.win_count[: wi.n_windows].double()
+            sq_cache[id(wi)] = float((cnt * cnt).sum().item())
+        a_flop += 4.0 * c * sq_cache[id(wi)]
+        a_ms += e0.elapsed_time(e1)
+    attn_tf = a_flop / a_ms / 1e9 if a_ms > 0 else 0.0
+    global ATTENTION_REPORT
+    ATTENTION_REPORT = {
+        "bound": "mfma", "kernel": "attn_prepare_fwd + attn_core_fwd (18 encoder layers of one forward)",
+        "achieved": round(attn_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(attn_tf / 2500.0, 5),
+        "note": "algorithmic 4*C*sum(n_w^2) FLOPs per layer / HIP-event time; the kernels execute 3 bf16 MFMAs "
+                "per product (split-bf16) on 16x32-token tiles, so executed MFMA FLOPs are >= 3x the algorithmic",
+        "layers": len(attn_records), "gflop_per_forward": round(a_flop / 1e9, 2), "ms_per_forward": round(a_ms, 3)}
     pairs_cache, tot_bytes, tot_ms = {}, 0.0, 0.0
     per_layer = []
     for nbr, cin, cout, e0, e1 in records:
@@ -224,6 +254,7 @@ def main():
             "fwd_only": {"value": round(n_pts_f / dt_f, 1), "unit": "points/s",
                          "ms_per_step": round(dt_f / args.steps * 1e3, 3)},
             "roofline": roof,
+            "attention_roofline": ATTENTION_REPORT,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scenes_np[0], cfg, ds, model, args.cpu_points)

@@ -147,6 +147,16 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
  * input-gradient GEMMs stay on rocBLAS/hipBLASLt.  cin, cout multiples of 4. */
 int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
                        void* stream);
+/* a6, a22  forward / input gradient of the same layers: y[m, cout] = x[m, cin] . W^T + bias, as the
+ * single-offset case of the split-bf16 gather-GEMM kernel (W fragments staged through LDS once per
+ * 128-row tile).  weight is torch's [cout, cin]; transpose=1 packs W itself as the operand, i.e.
+ * dx[m, cin] = dy[m, cout] . W is seg3d_linear_fwd(dy, ..., cin_of_call = cout, cout_of_call = cin).
+ * Operand rows (cin of the call) must be a multiple of 8, columns (cout of the call) a multiple of 16. */
+size_t seg3d_linear_packed_bytes(int32_t cin, int32_t cout, int32_t transpose);
+int seg3d_linear_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t transpose,
+                             void* w_packed, void* stream);
+int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
+                     int32_t cin, int32_t cout, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /

@@ -13,8 +13,9 @@
 // Algorithmic bytes per launch: P*(Cin+Cout)*4 + 27*Cin*Cout*4 + P*8, P = active pairs.
 #include "common.hpp"
 
-size_t spconv_split_packed_bytes(int cin_op, int cout_op);
-int spconv_split_pack(const float* weight, int cin, int cout, int transpose, int flip, void* w_packed, hipStream_t st);
+size_t spconv_split_packed_bytes(int cin_op, int cout_op, int kk);
+int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transpose, int flip, void* w_packed,
+                      hipStream_t st);
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
                      int cout, float* y, hipStream_t st);
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
@@ -275,7 +276,7 @@ extern "C" {
 size_t seg3d_spconv_packed_bytes(int32_t cin, int32_t cout, int32_t flags) {
     if (cin <= 0 || cout <= 0) return 0;
     const int cin_op = (flags & 1) ? cout : cin, cout_op = (flags & 1) ? cin : cout;
-    if (flags & 4) return spconv_split_packed_bytes(cin_op, cout_op);
+    if (flags & 4) return spconv_split_packed_bytes(cin_op, cout_op, 27);
     return (size_t)27 * cin * cout * sizeof(float);
 }
 
@@ -283,7 +284,7 @@ int seg3d_spconv_pack_weight(const float* weight, int32_t cin, int32_t cout, int
                              void* stream) {
     if (!weight || !w_packed || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15)) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (flags & 4) return spconv_split_pack(weight, cin, cout, flags & 1, (flags >> 1) & 1, w_packed, st);
+    if (flags & 4) return spconv_split_pack(weight, cin, cout, 27, flags & 1, (flags >> 1) & 1, w_packed, st);
     const int64_t total = (int64_t)27 * cin * cout;
     hipLaunchKernelGGL(pack_weight, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout,
                        flags & 1, (flags >> 1) & 1, static_cast<float*>(w_packed));

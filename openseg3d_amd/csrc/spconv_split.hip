@@ -46,12 +46,12 @@ __device__ __forceinline__ void split8(const f32x4& p, const f32x4& q, bf16x8* h
 
 // packed stream: [k'][cin_op/32 (padded)][cout_op/16][2: hi,lo][64 lanes][8 bf16];
 // lane = (ci%32)/8 * 16 + co%16, element j = ci%8
-__global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict__ w, int cin_src, int cout_src,
+__global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict__ w, int cin_src, int cout_src, int kk,
                                                          int transpose, int flip, __bf16* __restrict__ wp) {
     const int cin_op = transpose ? cout_src : cin_src;
     const int cout_op = transpose ? cin_src : cout_src;
     const int cb_n = (cin_op + 31) / 32, nb_n = cout_op / 16;
-    const int64_t total = (int64_t)27 * cb_n * nb_n * 1024;
+    const int64_t total = (int64_t)kk * cb_n * nb_n * 1024;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     int64_t r = t;
@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict
     const int co_op = nb * 16 + (lane & 15);
     float v = 0.f;
     if (ci_op < cin_op) {
-        const int k = flip ? 26 - kp : kp;
+        const int k = flip ? kk - 1 - kp : kp;
         const int ci = transpose ? co_op : ci_op;
         const int co = transpose ? ci_op : co_op;
-        v = w[((int64_t)co * 27 + k) * cin_src + ci];
+        v = w[((int64_t)co * kk + k) * cin_src + ci];
     }
     const __bf16 hi = (__bf16)v;
     wp[t] = h ? (__bf16)(v - (float)hi) : hi;
@@ -101,12 +101,16 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         const int64_t r = row0 + (lane & (RB * 16 - 1));
         const bool ok = r < m_out;
         const int64_t rc = ok ? r : last_row;
-        int32_t v[27];
+        if (nbr == nullptr) {  // dense rows (Linear layer): one "offset", neighbour of row r is row r
+            my_mask = 1u;
+        } else {
+            int32_t v[27];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)k * m_out + rc];
+            for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)k * m_out + rc];
 #pragma unroll
-        for (int k = 0; k < 27; ++k)
-            if (__ballot(ok && v[k] >= 0) != 0ull) my_mask |= 1u << k;
+            for (int k = 0; k < 27; ++k)
+                if (__ballot(ok && v[k] >= 0) != 0ull) my_mask |= 1u << k;
+        }
     }
     if (lane == 0) wave_mask[wave] = my_mask;
     __syncthreads();
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             bool any = false;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int32_t v = nbr[(int64_t)k * m_out + grow[rb]];
+                const int32_t v = nbr ? nbr[(int64_t)k * m_out + grow[rb]] : (int32_t)grow[rb];
                 idx[rb] = grow_ok[rb] ? v : -1;
                 any |= idx[rb] >= 0;
             }
@@ -261,14 +265,15 @@ int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* 
 }  // namespace
 
 // ---- internal entry points used by spconv.hip
-size_t spconv_split_packed_bytes(int cin_op, int cout_op) {
-    return (size_t)27 * ((cin_op + 31) / 32) * (cout_op / 16) * 1024 * sizeof(__bf16);
+size_t spconv_split_packed_bytes(int cin_op, int cout_op, int kk) {
+    return (size_t)kk * ((cin_op + 31) / 32) * (cout_op / 16) * 1024 * sizeof(__bf16);
 }
 
-int spconv_split_pack(const float* weight, int cin, int cout, int transpose, int flip, void* w_packed, hipStream_t st) {
+int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transpose, int flip, void* w_packed,
+                      hipStream_t st) {
     const int cin_op = transpose ? cout : cin, cout_op = transpose ? cin : cout;
-    const int64_t total = (int64_t)27 * ((cin_op + 31) / 32) * (cout_op / 16) * 1024;
-    hipLaunchKernelGGL(pack_weight_split, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout,
+    const int64_t total = (int64_t)kk * ((cin_op + 31) / 32) * (cout_op / 16) * 1024;
+    hipLaunchKernelGGL(pack_weight_split, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout, kk,
                        transpose, flip, reinterpret_cast<__bf16*>(w_packed));
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
@@ -284,3 +289,31 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
     if (nb % 2 == 0) return launch_split<2, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
     return launch_split<1, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
 }
+
+// ------------------------------------------------------------------ dense Linear layers through the same kernel
+// a6 / a22: y = x W^T + b on [rows, C] activations (segformer.py:21-32,58-76, point_transformer_layer.py:260-276,
+// cosine_msa.py:58-63,403).  A Linear layer is the single-offset case of the kernel above (identity neighbour
+// table): W fragments staged through LDS once per 128-row tile, rows streamed with 32-B loads, split-bf16 MFMA.
+extern "C" {
+
+size_t seg3d_linear_packed_bytes(int32_t cin, int32_t cout, int32_t transpose) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return spconv_split_packed_bytes(transpose ? cout : cin, transpose ? cin : cout, 1);
+}
+
+int seg3d_linear_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t transpose, void* w_packed,
+                             void* stream) {
+    const int cin_op = transpose ? cout : cin, cout_op = transpose ? cin : cout;
+    if (!weight || !w_packed || cin <= 0 || cout <= 0 || (cin_op & 7) || (cout_op & 15)) return SEG3D_EINVAL;
+    return spconv_split_pack(weight, cin, cout, 1, transpose ? 1 : 0, 0, w_packed, as_stream(stream));
+}
+
+int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias, int32_t cin, int32_t cout,
+                     float* y, void* stream) {
+    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!x || !y) return SEG3D_EINVAL;
+    return spconv_split_fwd(x, nullptr, m, w_packed, bias, cin, cout, y, as_stream(stream));
+}
+
+}  // extern "C"

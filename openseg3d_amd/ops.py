@@ -249,39 +249,75 @@ def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None):
 
 
 # ------------------------------------------------------------------------------------------ a6/a22 dense layers
+def _linear_pack(weight, transpose):
+    """MFMA fragment stream of a Linear weight (or of a row slice of one, e.g. in_proj_weight[:2C]).  Cached on
+    the owning parameter object, keyed by slice and validated by the tensor version (weights are static in eval)."""
+    owner = weight._base if weight._base is not None else weight
+    cache = owner.__dict__.setdefault("_seg3d_packs", {})
+    key = (weight.storage_offset(), tuple(weight.shape), int(transpose))
+    hit = cache.get(key)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    w = _f32c(weight)
+    cout, cin = w.shape
+    out = torch.empty((_lib.query("seg3d_linear_packed_bytes", cin, cout, int(transpose)),), dtype=torch.uint8,
+                      device=w.device)
+    _lib.call("seg3d_linear_pack_weight", _ptr(w), cin, cout, int(transpose), _ptr(out), _stream())
+    cache[key] = (weight._version, out)
+    return out
+
+
+def _linear_apply(x, packed, bias, cin, cout):
+    y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
+    _lib.call("seg3d_linear_fwd", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), cin, cout, _ptr(y), _stream())
+    return y
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b with torch GEMMs for y and dx; dW through the split-bf16 tall-skinny kernel."""
+    """y = x W^T + b on [rows, C] activations: forward and input gradient as the single-offset case of the
+    split-bf16 gather-GEMM kernel, weight gradient through the tall-skinny split-bf16 kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, exact):
+        x = _f32c(x)
+        cout, cin = weight.shape
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        ctx.has_bias, ctx.exact = bias is not None, exact
+        if exact:  # fp32 GEMM (rocBLAS/hipBLASLt); only the weight gradient uses the split kernel
+            return torch.nn.functional.linear(x, weight, bias)
+        return _linear_apply(x, _linear_pack(weight, 0), None if bias is None else _f32c(bias), cin, cout)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = _f32c(dy)
+        cout, cin = weight.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = dy @ weight
+            if not ctx.exact and cout % 8 == 0 and cin % 16 == 0:
+                dx = _linear_apply(dy, _linear_pack(weight, 1), None, cout, cin)
+            else:
+                dx = dy @ weight
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            _lib.call("seg3d_linear_wgrad", _ptr(_f32c(x)), _ptr(dy), x.shape[0], weight.shape[1], weight.shape[0],
-                      _ptr(dw), _stream())
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x, weight, bias=None):
-    """F.linear for [rows, C] activations; in training the weight gradient runs in libseg3d_hip.so."""
-    usable = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 4 == 0
-              and weight.shape[1] % 4 == 0 and torch.is_grad_enabled() and weight.requires_grad
-              and CONV_PRECISION == "bf16x3")
-    if not usable:
+def linear(x, weight, bias=None, exact=False):
+    """F.linear for [rows, C] activations.  Layers whose shape fits the MFMA tiles (cin % 8 == 0,
+    cout % 16 == 0) run in libseg3d_hip.so in split-bf16 arithmetic; the rest (6 -> 64 input layer, -> 22
+    classifiers) stay on rocBLAS.  ``exact=True`` keeps forward and input gradient on the fp32 GEMM and only
+    takes the weight gradient from the split kernel: used by the per-point MLPs, whose ~2^-16 relative forward
+    error would land directly on the O(25) logits (measured 1e-3 absolute) instead of being washed out by the
+    LayerNorms of the voxel path."""
+    fits = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 16 == 0
+            and weight.shape[1] % 8 == 0 and CONV_PRECISION == "bf16x3")
+    if not fits or (exact and not (torch.is_grad_enabled() and weight.requires_grad)):
         return torch.nn.functional.linear(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias, exact)
 
 
 # ------------------------------------------------------------------------------------------ a13-a18 windows

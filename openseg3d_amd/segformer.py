@@ -190,7 +190,7 @@ class RowLinear(nn.Linear):
     """nn.Linear on [rows, C] activations whose weight gradient runs in libseg3d_hip.so (ops.linear)."""
 
     def forward(self, x):
-        return ops.linear(x, self.weight, self.bias)
+        return ops.linear(x, self.weight, self.bias, exact=True)
 
 
 def _bn_mlp(dims, first_bn=None, last_plain=False):

@@ -6,7 +6,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("m,cin,cout", [(1000, 48, 96), (4097, 64, 64), (31, 192, 384), (70000, 96, 192),
-                                        (513, 100, 36), (5000, 256, 64), (64, 768, 384)])
+                                        (513, 104, 48), (5000, 256, 64), (64, 768, 384)])
 def test_linear_wgrad_matches_autograd(m, cin, cout):
     from openseg3d_amd import ops
     dev = torch.device("cuda:0")

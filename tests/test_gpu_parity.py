@@ -281,9 +281,9 @@ def test_swformer_block_matches_reference(dev, golden_dir, name):
     with torch.no_grad():
         a0 = blk.layers[0].win_attn(feats, plan.pos[0], plan.index[0])
         y = blk({"voxel_features": feats, "plan": plan})
-    # fp32 end to end; outputs are O(1-5): 2e-5 abs is ~1e-5 relative
-    assert float(np.abs(_np(a0) - d[name + "_attn0"]).max()) < 2e-5
-    assert float(np.abs(_np(y) - d[name + "_out"]).max()) < 5e-5
+    # split-bf16 projections / attention (~2^-16 relative per product), fp32 LayerNorm/softmax; outputs are O(1-5)
+    assert float(np.abs(_np(a0) - d[name + "_attn0"]).max()) < 2e-4
+    assert float(np.abs(_np(y) - d[name + "_out"]).max()) < 3e-4
 
 
 def test_window_attention_backward_vs_oracle_autograd(dev, golden_dir):
