@@ -230,6 +230,31 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a12, a22  row-wise normalisation layers on [m, c] features (c multiple of 4).
+ * LayerNorm of the post-norm encoder layer (point_transformer_layer.py:289-298), fused with the residual:
+ *     y = res + (x - mean_row) * rstd_row * gamma + beta        (res may be NULL; mean/rstd [m] kept for bwd)
+ * backward: dx, and dgamma/dbeta [c] (zeroed inside, accumulated with one float atomic per channel per block);
+ * the residual's gradient is dy itself.
+ * BatchNorm1d (+ residual) (+ ReLU) of the conv blocks / point MLPs (spconv_utils.py:13-32,
+ * pointtransformer.py:47-66, segformer.py:21-76):
+ *     seg3d_colstats   sums[0..c) = sum_r (x - x[0]), sums[c..2c) = sum_r (x - x[0])^2   (shifted, cancellation-free)
+ *     seg3d_affine_act y = act(x * scale + shift (+ res)), scale/shift [c] folded from the statistics by the caller
+ *     seg3d_batchnorm_bwd  g = dy masked by (y > 0) when relu; dres = g (may be NULL);
+ *                      dx = gamma*rstd*(g - mean_r(g) - xhat*mean_r(g*xhat)); sums = {dbeta, dgamma}
+ */
+int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                        int64_t m, int32_t c, float* y, float* mean, float* rstd, void* stream);
+int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta,
+                        void* stream);
+int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* stream);
+int seg3d_affine_act(const float* x, const float* res, const float* scale, const float* shift, int32_t relu,
+                     int64_t m, int32_t c, float* y, void* stream);
+int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, int32_t relu, int64_t m, int32_t c, float* dx, float* dres,
+                        float* sums, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * a7, a25, a26  torch_scatter.scatter(src, index, dim=0, reduce='mean'|'max') at
  *      seg3d/models/voxel_encoders/vfe.py:24-25, seg3d/models/layers/se_layer.py:24-28, and
  *      voxel_pooling_ext.voxel_pooling_{forward,backward}_* -- seg3d/ops/voxel_pooling/src/

@@ -320,6 +320,115 @@ def linear(x, weight, bias=None, exact=False):
     return _LinearFn.apply(x, weight, bias, exact)
 
 
+# ------------------------------------------------------------------------------------------ a12/a22 norms
+class _LayerNormResidualFn(torch.autograd.Function):
+    """y = res + LayerNorm(x) (res optional)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        x = _f32c(x)
+        m, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((m,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((m,), dtype=torch.float32, device=x.device)
+        r = None if res is None else _f32c(res)
+        _lib.call("seg3d_layernorm_fwd", _ptr(x), _ptr(r), _ptr(gamma), _ptr(beta), float(eps), m, c, _ptr(y),
+                  _ptr(mean), _ptr(rstd), _stream())
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        m, c = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), dtype=torch.float32, device=x.device)
+        db = torch.empty((c,), dtype=torch.float32, device=x.device)
+        _lib.call("seg3d_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), m, c, _ptr(dx),
+                  _ptr(dg), _ptr(db), _stream())
+        return dx, (dy if ctx.has_res else None), dg, db, None
+
+
+def layer_norm_residual(x, res, ln):
+    """res + ln(x) for an nn.LayerNorm over the last dim of [rows, C] (C % 4 == 0, C <= 512)."""
+    c = x.shape[1]
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and c % 4 == 0 and c <= 512
+            and ln.elementwise_affine and ln.bias is not None):
+        y = ln(x)
+        return y if res is None else res + y
+    return _LayerNormResidualFn.apply(x, res, ln.weight, ln.bias, ln.eps)
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over rows (+ residual) (+ ReLU); statistics are computed in forward."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, mean, rstd, relu):
+        x = _f32c(x)
+        m, c = x.shape
+        scale = gamma * rstd
+        shift = beta - mean * scale
+        y = torch.empty_like(x)
+        r = None if res is None else _f32c(res)
+        _lib.call("seg3d_affine_act", _ptr(x), _ptr(r), _ptr(scale), _ptr(shift), int(relu), m, c, _ptr(y), _stream())
+        ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.relu, ctx.has_res = relu, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        m, c = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        _lib.call("seg3d_batchnorm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), int(ctx.relu),
+                  m, c, _ptr(dx), _ptr(dres), _ptr(sums), _stream())
+        return dx, dres, sums[1], sums[0], None, None, None
+
+
+def batch_norm_act(x, bn, relu=True, res=None):
+    """act(bn(x) (+ res)) for an nn.BatchNorm1d over [rows, C] features (C % 4 == 0), relu optional.
+    Training: batch statistics (biased variance for the normalisation, unbiased into running_var, as torch);
+    eval: running statistics folded into one affine pass."""
+    c = x.shape[1]
+    fits = x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and c % 4 == 0 and c <= 1024 and bn.affine
+    use_batch = bn.training or not bn.track_running_stats
+    if not fits or (not use_batch and torch.is_grad_enabled() and x.requires_grad) or x.shape[0] < 2:
+        y = bn(x)
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if relu else y
+    if use_batch:
+        xc = _f32c(x)
+        m = xc.shape[0]
+        with torch.no_grad():
+            sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+            _lib.call("seg3d_colstats", _ptr(xc), m, c, _ptr(sums), _stream())
+            d = sums[0] / m
+            mean = xc[0] + d
+            var = (sums[1] / m - d * d).clamp_(min=0.0)
+            rstd = torch.rsqrt(var + bn.eps)
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (m / (m - 1)), alpha=mom)
+        return _BatchNormActFn.apply(xc, res, bn.weight, bn.bias, mean, rstd, bool(relu))
+    with torch.no_grad():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        xc = _f32c(x)
+        y = torch.empty_like(xc)
+        r = None if res is None else _f32c(res)
+        _lib.call("seg3d_affine_act", _ptr(xc), _ptr(r), _ptr(scale), _ptr(shift), int(relu), xc.shape[0], c, _ptr(y),
+                  _stream())
+    return y
+
+
 # ------------------------------------------------------------------------------------------ a13-a18 windows
 class WindowIndex:
     """Outputs of seg3d_window_partition for one (stage, shift)."""

@@ -38,7 +38,35 @@ def conv_module(cin, cout, norm_fn, act_fn, conv_type="subm", indice_key=None):
         conv = spconv.SparseInverseConv3d(cin, cout, 3, bias=False, indice_key=indice_key)
     else:
         raise NotImplementedError(conv_type)
-    return spconv.SparseSequential(conv, norm_fn(cout), act_fn)
+    return ConvBnAct(conv, norm_fn(cout), act_fn)
+
+
+class ConvBnAct(spconv.SparseSequential):
+    """conv -> BatchNorm1d -> ReLU with the reference's child names; BN + ReLU run as one fused pass."""
+
+    def forward(self, x):
+        conv, bn = self._modules["0"], self._modules["1"]
+        y = conv(x)
+        return y.replace_feature(ops.batch_norm_act(y.features, bn, relu=True))
+
+
+class FusedMLP(nn.Sequential):
+    """nn.Sequential of Linear / BatchNorm1d / ReLU / Dropout in which every (BatchNorm1d, ReLU) pair runs as
+    one fused pass (same modules, same state_dict keys)."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.BatchNorm1d) and not isinstance(m, NarrowBatchNorm1d):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = ops.batch_norm_act(x, m, relu=relu)
+                i += 2 if relu else 1
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class VFE(nn.Module):
@@ -87,9 +115,9 @@ class SparseBasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         y = self.conv1(x)
-        y = y.replace_feature(self.act(self.bn1(y.features)))
+        y = y.replace_feature(ops.batch_norm_act(y.features, self.bn1, relu=True))
         y = self.conv2(y)
-        return y.replace_feature(self.act(self.bn2(y.features) + x.features))
+        return y.replace_feature(ops.batch_norm_act(y.features, self.bn2, relu=True, res=x.features))
 
 
 class UpBlock(spconv.SparseModule):
@@ -121,7 +149,7 @@ class PointTransformer(nn.Module):
         self.act_fn = nn.ReLU(inplace=True)
         norm_fn, act_fn = self.norm_fn, self.act_fn
 
-        self.conv_input = spconv.SparseSequential(
+        self.conv_input = ConvBnAct(
             spconv.SubMConv3d(input_channels, 48, 3, padding=1, bias=False, indice_key="subm1"), norm_fn(48), act_fn)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(self.depths))]
         widths = (48, 96, 192, 384)
@@ -202,7 +230,7 @@ def _bn_mlp(dims, first_bn=None, last_plain=False):
             mods.append(RowLinear(dims[i], dims[i + 1]))
         else:
             mods += [RowLinear(dims[i], dims[i + 1], bias=False), nn.BatchNorm1d(dims[i + 1]), nn.ReLU(inplace=True)]
-    return nn.Sequential(*mods)
+    return FusedMLP(*mods)
 
 
 class Segformer(nn.Module):
@@ -227,8 +255,8 @@ class Segformer(nn.Module):
         self.fusion_encoder = _bn_mlp([self.point_feature_channel + self.voxel_feature_channel, 256, 128,
                                        self.fusion_feature_channel])
         self.se = FlattenSELayer(self.fusion_feature_channel)
-        self.classifier = nn.Sequential(nn.Linear(self.fusion_feature_channel, 64, bias=False), nn.BatchNorm1d(64),
-                                        nn.ReLU(True), nn.Dropout(0.3),
+        self.classifier = FusedMLP(RowLinear(self.fusion_feature_channel, 64, bias=False), nn.BatchNorm1d(64),
+                                   nn.ReLU(True), nn.Dropout(0.3),
                                         nn.Linear(64, dataset.num_classes, bias=False))
         self.weight_initialization()
 

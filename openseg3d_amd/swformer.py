@@ -175,8 +175,12 @@ class EncoderLayer(nn.Module):
         self.drop_path_rate = float(drop_path_rate)
 
     def forward(self, x, pos, wi):
-        x = x + drop_path(self.norm1(self.win_attn(x, pos, wi)), self.drop_path_rate, self.training)
-        return x + drop_path(self.norm2(self.mlp(x)), self.drop_path_rate, self.training)
+        a = self.win_attn(x, pos, wi)
+        if self.drop_path_rate == 0.0 or not self.training:  # fused residual + LayerNorm
+            x = ops.layer_norm_residual(a, x, self.norm1)
+            return ops.layer_norm_residual(self.mlp(x), x, self.norm2)
+        x = x + drop_path(ops.layer_norm_residual(a, None, self.norm1), self.drop_path_rate, True)
+        return x + drop_path(ops.layer_norm_residual(self.mlp(x), None, self.norm2), self.drop_path_rate, True)
 
 
 class SWFormerBlock(nn.Module):

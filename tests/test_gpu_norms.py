@@ -1,0 +1,88 @@
+"""GPU parity of the fused row-wise normalisation passes (rownorm.hip) against torch's fp64 reference."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,c", [(1000, 48), (4099, 96), (257, 192), (3000, 384), (5, 32), (70001, 96)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_layernorm_residual_forward_backward(m, c, with_res):
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m + c)
+    x = torch.randn(m, c) * 2 + 0.5
+    r = torch.randn(m, c)
+    g = torch.randn(m, c)
+    ln = nn.LayerNorm(c)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(c))
+        ln.bias.copy_(0.1 * torch.randn(c))
+    ref_ln = nn.LayerNorm(c).double()
+    ref_ln.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    xr, rr = x.double().requires_grad_(), r.double().requires_grad_()
+    yr = ref_ln(xr) + (rr if with_res else 0)
+    yr.backward(g.double())
+
+    ln = ln.to(dev)
+    xg, rg = x.to(dev).requires_grad_(), r.to(dev).requires_grad_()
+    y = ops.layer_norm_residual(xg, rg if with_res else None, ln)
+    assert "LayerNormResidual" in type(y.grad_fn).__name__
+    y.backward(g.to(dev))
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 2e-5
+    if with_res:
+        assert float((rg.grad.cpu().double() - rr.grad).abs().max()) < 1e-6
+    for got, ref in ((ln.weight.grad, ref_ln.weight.grad), (ln.bias.grad, ref_ln.bias.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("m,c", [(1000, 48), (4099, 96), (300, 256), (70001, 64), (2, 32)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m * 3 + c)
+    x = torch.randn(m, c) * 1.5 + 3.0  # non-zero mean: exercises the shifted statistics
+    r = torch.randn(m, c)
+    g = torch.randn(m, c)
+    bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(c))
+        bn.bias.copy_(0.1 * torch.randn(c))
+        bn.running_mean.copy_(torch.randn(c))
+        bn.running_var.copy_(0.5 + torch.rand(c))
+    ref = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+
+    def ref_fwd(mod, xx, rr_):
+        y = mod(xx)
+        if with_res:
+            y = y + rr_
+        return torch.relu(y) if relu else y
+
+    # ---- training
+    xr, rr = x.double().requires_grad_(), r.double().requires_grad_()
+    yr = ref_fwd(ref.train(), xr, rr)
+    yr.backward(g.double())
+    bn = bn.to(dev).train()
+    xg, rg = x.to(dev).requires_grad_(), r.to(dev).requires_grad_()
+    y = ops.batch_norm_act(xg, bn, relu=relu, res=rg if with_res else None)
+    assert "BatchNormAct" in type(y.grad_fn).__name__
+    y.backward(g.to(dev))
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 5e-5
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 5e-5
+    if with_res:
+        assert float((rg.grad.cpu().double() - rr.grad).abs().max()) < 1e-6
+    for got, want in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
+        assert float((got.cpu().double() - want).abs().max()) < 1e-3 * max(1.0, float(want.abs().max()))
+    assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) < 1e-5
+    assert float((bn.running_var.cpu().double() - ref.running_var).abs().max()) < 1e-4
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+    # ---- eval (running statistics)
+    with torch.no_grad():
+        ye = ops.batch_norm_act(x.to(dev), bn.eval(), relu=relu, res=r.to(dev) if with_res else None)
+        yre = ref_fwd(ref.eval(), x.double(), r.double())
+    assert float((ye.cpu().double() - yre).abs().max()) < 5e-5
