@@ -194,7 +194,8 @@ def main():
     opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)  # configs/waymo_one_sweep.yaml
     net = model
     if train and world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
+                                                        broadcast_buffers=False, gradient_as_bucket_view=True)
     labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
     ce = torch.nn.functional.cross_entropy
 
