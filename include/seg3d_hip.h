@@ -277,6 +277,17 @@ int seg3d_segment_reduce_bwd(const float* dout, int32_t c, const int32_t* seg_of
 int seg3d_gather_rows(const float* feats, const int32_t* ids, int64_t n, int32_t c, float* out,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f) rank 1  knn_query_ext.knn_query_cuda -- seg3d/ops/knn_query/src/knn_query_cuda.cu:67-133,
+ *      wrapper seg3d/ops/knn_query/knn_query.py:7-24 (callers: DeepFusionBlock deep_fusion.py:31, tools/train.py:103).
+ * For every query row of new_xyz [m,3] the k nearest rows of xyz [n,3] inside the same batch segment
+ * (offset / new_offset: cumulative int32 counts per sample), ascending squared distance; ties by ascending
+ * candidate index; slots beyond the segment size hold (1e10, segment start) as in the reference.  k <= 64.
+ */
+int seg3d_knn_query(const float* xyz, int64_t n, const float* new_xyz, int64_t m, const int32_t* offset,
+                    const int32_t* new_offset, int32_t batch_size, int32_t k, int32_t* idx, float* dist2,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

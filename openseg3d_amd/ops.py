@@ -616,3 +616,28 @@ def voxel_avg_pooling(feats, coords, counts):
     ids = _i32c(coords)
     ids = torch.where((ids >= 0) & (ids < m), ids, torch.full_like(ids, -1))
     return segment_reduce(feats, SegmentIndex(ids, m), REDUCE_MEAN)
+
+
+# ------------------------------------------------------------------------------------------ kNN
+def knn_query(nsample, xyz, new_xyz, offset, new_offset):
+    """``seg3d.ops.knn_query`` (knn_query.py:7-24): (idx int32 [m, nsample], dist float32 [m, nsample] = sqrt(d2)).
+    xyz / new_xyz: contiguous float32 [*, 3]; offset / new_offset: cumulative int32 counts per sample.
+    Non-differentiable, like the reference Function (it defines no backward)."""
+    if new_xyz is None:
+        new_xyz = xyz
+    _need_gpu(xyz, new_xyz, offset, new_offset)
+    if xyz.dim() != 2 or new_xyz.dim() != 2 or not xyz.is_contiguous() or not new_xyz.is_contiguous():
+        raise _lib.Seg3dError("knn_query: xyz and new_xyz must be contiguous 2-D tensors (knn_query.py:16)")
+    xyz, new_xyz = xyz.detach(), new_xyz.detach()
+    if xyz.dtype != torch.float32 or new_xyz.dtype != torch.float32:
+        raise _lib.Seg3dError("knn_query: float32 coordinates expected")
+    # The CUDA kernel reads both buffers with a stride of 3 floats whatever their second dimension is
+    # (knn_query_cuda.cu:97-99): n and m are taken from shape[0] and the memory is reinterpreted, which is
+    # what happens when DeepFusionBlock passes [N, 6] points (SURVEY 2.2 "latent bug").  Reproduced as is.
+    n, m = xyz.shape[0], new_xyz.shape[0]
+    off, noff = _i32c(offset), _i32c(new_offset)
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    d2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+    _lib.call("seg3d_knn_query", _ptr(xyz), n, _ptr(new_xyz), m, _ptr(off), _ptr(noff), off.shape[0], int(nsample),
+              _ptr(idx), _ptr(d2), _stream())
+    return idx, torch.sqrt(d2)

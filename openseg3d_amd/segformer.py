@@ -10,8 +10,8 @@ What runs where: voxel-feature reduce, every sparse convolution, window partitio
 the voxel->point gather run in libseg3d_hip.so; per-point / per-voxel dense layers (Linear, BN, LN,
 GELU) stay on torch's GEMM / elementwise kernels.  Index structures (site levels, neighbour tables,
 window CSRs, point->voxel CSR) are built once per batch and shared by all layers that use them.
-Scope: single-sweep, no image fusion (configs/waymo_one_sweep*.yaml); the multi-sweep / DeepFusion
-branch raises NotImplementedError.
+Scope: all three shipped configs -- single sweep (cartesian / cylinder) and multi-sweep with optional
+image-feature fusion (DeepFusionBlock over seg3d_knn_query).
 """
 from collections import OrderedDict
 from functools import partial
@@ -233,31 +233,65 @@ def _bn_mlp(dims, first_bn=None, last_plain=False):
     return FusedMLP(*mods)
 
 
+class DeepFusionBlock(nn.Module):
+    """Point <-> image-feature cross attention over the k nearest current-sweep points
+    (seg3d/models/layers/deep_fusion.py:10-45).  Neighbour search = seg3d_knn_query; the reference hands
+    ``knn_query`` its [N, 6|8] point rows although the kernel strides by 3 floats: with
+    ``faithful_stride=True`` (default) the same buffer is handed over, so outputs match the reference bit for
+    bit in the neighbour sets; ``False`` searches on the xyz columns, which is what the code presumably meant."""
+
+    def __init__(self, lidar_channel, image_channel, hidden_channel, n_neighbors, attn_pdrop=0.3, faithful_stride=True):
+        super().__init__()
+        self.n_neighbors, self.faithful_stride = n_neighbors, faithful_stride
+        self.q_embedding = nn.Linear(lidar_channel, hidden_channel)
+        self.k_embedding = nn.Linear(image_channel, hidden_channel)
+        self.v_embedding = nn.Linear(image_channel, hidden_channel)
+        self.attn_dropout = nn.Dropout(attn_pdrop)
+        self.c_proj = nn.Linear(hidden_channel, image_channel)
+
+    def forward(self, points, point_id_offset, lidar_features, image_features):
+        q = self.q_embedding(lidar_features)
+        k = self.k_embedding(image_features)
+        v = self.v_embedding(image_features)
+        xyz = points.contiguous() if self.faithful_stride else points[:, :3].contiguous()
+        knn_ids, _ = ops.knn_query(self.n_neighbors, xyz, xyz, point_id_offset, point_id_offset)
+        knn_ids = knn_ids.long()
+        attn = torch.einsum("nc,nkc->nk", q, k[knn_ids]) / (q.shape[-1] ** 0.5)
+        invalid = (image_features.sum(dim=1) == 0)[knn_ids]
+        attn = attn.masked_fill(invalid, float("-inf"))
+        attn = torch.nan_to_num(torch.softmax(attn, dim=-1))
+        attn = self.attn_dropout(attn)
+        return self.c_proj(torch.einsum("nk,nkc->nc", attn, v[knn_ids]))
+
+
 class Segformer(nn.Module):
     def __init__(self, dataset, batching_info, window_shape, depths, drop_path_rate):
         super().__init__()
         dim_point = dataset.dim_point + (2 if dataset.use_cylinder else 0)
-        if dataset.use_multi_sweeps or dataset.use_image_feature:
-            raise NotImplementedError("multi-sweep / image-fusion inputs are the next scope row (SURVEY.md 8f)")
-        self.use_multi_sweeps = False
-        self.use_image_feature = False
+        self.use_multi_sweeps = bool(dataset.use_multi_sweeps)
+        self.use_image_feature = bool(dataset.use_image_feature)
         self.point_feature_channel = 64
         self.point_encoder = _bn_mlp([dim_point, 64, 128, 256, self.point_feature_channel], first_bn=dim_point,
                                      last_plain=True)
-        self.vfe = VFE(self.point_feature_channel, reduce="max")
+        # multi-sweep: the voxel features are the MEAN of the raw rows of all sweeps (segformer.py:34-37,105-107)
+        self.vfe = VFE(dim_point, reduce="mean") if self.use_multi_sweeps else VFE(self.point_feature_channel, "max")
         self.scatter = VFE(3, reduce="mean")  # present (and unused) in the reference: segformer.py:39
         self.voxel_feature_channel = 32
         self.point_transformer = PointTransformer(
             self.vfe.voxel_feature_channel, self.voxel_feature_channel, dataset.grid_size, dataset.voxel_size,
             dataset.point_cloud_range, batching_info=batching_info, window_shape=window_shape, depths=depths,
             drop_path_rate=drop_path_rate, num_classes=dataset.num_classes)
+        self.image_feature_channel = dataset.dim_image_feature if self.use_image_feature else 0
+        if self.use_image_feature:
+            self.deep_fusion = DeepFusionBlock(self.point_feature_channel + self.voxel_feature_channel,
+                                               self.image_feature_channel, 32, 16)
         self.fusion_feature_channel = 64
-        self.fusion_encoder = _bn_mlp([self.point_feature_channel + self.voxel_feature_channel, 256, 128,
-                                       self.fusion_feature_channel])
+        self.fusion_encoder = _bn_mlp([self.point_feature_channel + self.voxel_feature_channel
+                                       + self.image_feature_channel, 256, 128, self.fusion_feature_channel])
         self.se = FlattenSELayer(self.fusion_feature_channel)
         self.classifier = FusedMLP(RowLinear(self.fusion_feature_channel, 64, bias=False), nn.BatchNorm1d(64),
                                    nn.ReLU(True), nn.Dropout(0.3),
-                                        nn.Linear(64, dataset.num_classes, bias=False))
+                                   nn.Linear(64, dataset.num_classes, bias=False))
         self.weight_initialization()
 
     def weight_initialization(self):
@@ -275,23 +309,38 @@ class Segformer(nn.Module):
         points = batch_dict["points"][:, 1:]
         ids = batch_dict["point_voxel_ids"]
         n_voxels = batch_dict["voxel_coords"].shape[0]
-        point_features = self.point_encoder(points)
-
-        # point <-> voxel CSR: built once, used by the VFE reduce and by the gather's backward
+        # point <-> voxel CSR over ALL rows: built once, used by the VFE reduce (and the gather's backward)
         seg = batch_dict.get("point_voxel_index")
         if seg is None:
             seg = ops.SegmentIndex(ids, n_voxels)
-        batch_dict["voxel_features"] = self.vfe(point_features, seg)
+
+        if self.use_multi_sweeps:
+            cur = points[:, 3] == 0  # rows of the current sweep: time lag column == 0 (segformer.py:98)
+            cur_rows = torch.nonzero(cur).view(-1)
+            cur_points = points[cur_rows]
+            cur_ids = seg.ids[cur_rows]
+            cur_seg = None
+            batch_rows = batch_dict["points"][cur_rows, 0]
+        else:
+            cur_points, cur_ids, cur_seg, batch_rows = points, seg.ids, seg, batch_dict["points"][:, 0]
+        point_features = self.point_encoder(cur_points)
+
+        batch_dict["voxel_features"] = self.vfe(points if self.use_multi_sweeps else point_features, seg)
         batch_dict = self.point_transformer(batch_dict)
 
-        point_voxel_features = ops.gather_rows(batch_dict["voxel_features"], seg.ids, seg)
-        fused = self.fusion_encoder(torch.cat([point_features, point_voxel_features], dim=1))
+        point_voxel_features = ops.gather_rows(batch_dict["voxel_features"], cur_ids, cur_seg)
+        fused = torch.cat([point_features, point_voxel_features], dim=1)
+        if self.use_image_feature:
+            img = self.deep_fusion(cur_points, batch_dict["point_id_offset"].int(), fused,
+                                   batch_dict["point_image_features"])
+            fused = torch.cat([fused, img], dim=1)
+        fused = self.fusion_encoder(fused)
 
-        # cumulative rows per sample: python ints from the batch builder, else the collated float tensor
+        # cumulative current-sweep rows per sample: python ints from the batch builder, else the collated tensor
         row_offsets = batch_dict.get("point_row_offsets")
         if row_offsets is None and batch_dict.get("point_id_offset") is not None:
             row_offsets = [int(v) for v in batch_dict["point_id_offset"].tolist()]
-        fused = fused + self.se(fused, batch_dict["points"][:, 0], row_offsets)
+        fused = fused + self.se(fused, batch_rows, row_offsets)
 
         result = OrderedDict()
         result["point_out"] = self.classifier(fused)

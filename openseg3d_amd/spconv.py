@@ -87,8 +87,10 @@ class _Conv3x3x3(SparseModule):
         ks = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
         if ks != 3 or dilation != 1:
             raise NotImplementedError("only 3x3x3, dilation 1 is on the OpenSeg3D path")
-        if in_channels % 16 or out_channels % 16:
-            raise NotImplementedError("channel counts must be multiples of 16 (MFMA 16x16x4 tiles)")
+        if out_channels % 16:
+            raise NotImplementedError("output channels must be a multiple of 16 (MFMA 16x16 tiles)")
+        # narrow inputs (the 6/8 raw point channels of the multi-sweep config) are zero-padded per call
+        self._pad_in = (-in_channels) % 16
         self.in_channels, self.out_channels = in_channels, out_channels
         self.stride, self.padding, self.indice_key = stride, padding, indice_key
         self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, 3, in_channels))
@@ -113,6 +115,10 @@ class _Conv3x3x3(SparseModule):
         return self._packed[1]
 
     def _apply_tables(self, feats, nbr, nbr_t, t_flags):
+        if self._pad_in:
+            feats = torch.nn.functional.pad(feats, (0, self._pad_in))
+            weight = torch.nn.functional.pad(self.weight, (0, self._pad_in))
+            return ops.sparse_conv(feats, weight, self.bias, nbr, nbr_t, t_flags, None)
         return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight())
 
     def extra_repr(self):

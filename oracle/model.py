@@ -65,16 +65,26 @@ def segformer_forward(batch, params, cfg):
     (seg3d/utils/data_utils.py:6-15): points f32 [N,1+D], point_voxel_ids i64 [N],
     voxel_coords f32 [M,4], batch_size int.  cfg: dict with grid_size (x,y,z),
     batching_info (list of 4 dicts with int keys), window_shape, depths.
-    Single-sweep, no image features (configs/waymo_one_sweep*.yaml).
+    cfg may set use_multi_sweeps / use_image_feature (configs/waymo_multi_sweeps.yaml): then batch also
+    carries point_id_offset (cumulative current-sweep rows) and point_image_features.
     Returns the reference's result OrderedDict plus the intermediates tests need.
     """
     p = params
     points = batch["points"][:, 1:]
     ids = batch["point_voxel_ids"]
-    pf = _point_encoder(points, p)
+    multi = bool(cfg.get("use_multi_sweeps", False))
+    if multi:
+        cur = points[:, 3] == 0  # segformer.py:98
+        cur_points = points[cur]
+    else:
+        cur_points = points
+    pf = _point_encoder(cur_points, p)
 
     ok = ids != -1
-    vox = sc.scatter(pf[ok], ids[ok], reduce="max")  # VFE(max), vfe.py:24-25
+    if multi:
+        vox = sc.scatter(points[ok], ids[ok], reduce="mean")  # VFE(dim_point, mean) over all sweeps, segformer.py:107
+    else:
+        vox = sc.scatter(pf[ok], ids[ok], reduce="max")  # VFE(max), vfe.py:24-25
 
     coords = batch["voxel_coords"].int().numpy()
     sparse_shape = np.asarray(cfg["grid_size"])[::-1]  # pointtransformer.py:120
@@ -107,14 +117,29 @@ def segformer_forward(batch, params, cfg):
     x = _up_block(x, feats[0], lvl[0].subm(), lvl[0].subm(), p, pre + "up1.")
     voxel_out = F.linear(x, p[pre + "voxel_classifier.0.weight"])
 
-    pv = sc.voxel_to_point(x, ids)
+    pv = sc.voxel_to_point(x, ids[cur] if multi else ids)
     f = torch.cat([pf, pv], dim=1)
+    if cfg.get("use_image_feature", False):  # DeepFusionBlock.forward, deep_fusion.py:26-45 (eval: no dropout)
+        from .knn import knn_query
+        img = batch["point_image_features"]
+        df = "deep_fusion."
+        q = F.linear(f, p[df + "q_embedding.weight"], p[df + "q_embedding.bias"])
+        kk = F.linear(img, p[df + "k_embedding.weight"], p[df + "k_embedding.bias"])
+        vv = F.linear(img, p[df + "v_embedding.weight"], p[df + "v_embedding.bias"])
+        off = batch["point_id_offset"].int()
+        nn_ids, _ = knn_query(16, cur_points.contiguous(), cur_points.contiguous(), off, off)
+        nn_ids = nn_ids.long()
+        w = torch.einsum("nc,nkc->nk", q, kk[nn_ids]) / np.sqrt(q.shape[-1])
+        w[(img.sum(dim=1) == 0)[nn_ids]] = float("-inf")
+        w = torch.nan_to_num(torch.softmax(w, dim=-1))
+        o = torch.einsum("nk,nkc->nc", w, vv[nn_ids])
+        f = torch.cat([f, F.linear(o, p[df + "c_proj.weight"], p[df + "c_proj.bias"])], dim=1)
     fe = "fusion_encoder."
     f = F.relu(_bn(F.linear(f, p[fe + "0.weight"]), p, fe + "1.", 1e-5))
     f = F.relu(_bn(F.linear(f, p[fe + "3.weight"]), p, fe + "4.", 1e-5))
     f = F.relu(_bn(F.linear(f, p[fe + "6.weight"]), p, fe + "7.", 1e-5))
 
-    bidx = batch["points"][:, 0].long()
+    bidx = (batch["points"][:, 0][cur] if multi else batch["points"][:, 0]).long()
     g = sc.scatter(f, bidx, reduce="mean")  # FlattenSELayer, se_layer.py:24-28
     g = torch.sigmoid(F.linear(F.relu(F.linear(g, p["se.fc.0.weight"])), p["se.fc.2.weight"]))
     f = f + f * g[bidx]

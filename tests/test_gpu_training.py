@@ -1,0 +1,67 @@
+"""GPU checks of the training path and of bench.py's output contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import refcfg
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_training_step_reaches_every_parameter():
+    """DDP runs with find_unused_parameters=False: every parameter must receive a gradient each step."""
+    from openseg3d_amd import batch as B, config, scene, segformer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = config.default_cfg()
+    ds = config.DatasetSpec(cfg)
+    model = segformer.build_segmentor(cfg, ds).to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    samples = [scene.make_small_scene(7, 6000, extent=9.0), scene.make_small_scene(8, 4000, extent=6.0)]
+    ce = torch.nn.functional.cross_entropy
+    losses = []
+    for _ in range(3):
+        b = B.make_batch(samples, ds.voxel_size, ds.point_cloud_range)
+        n = b["points"].shape[0]
+        labels = torch.arange(n, device=dev) % 22
+        opt.zero_grad(set_to_none=True)
+        res = model(b)
+        loss = (ce(res["point_out"], labels) + ce(res["voxel_out"], labels[:1].expand(res["voxel_out"].shape[0]))
+                + 0.4 * ce(res["aux_voxel_out"], labels[:1].expand(res["aux_voxel_out"].shape[0])))
+        loss.backward()
+        missing = [k for k, p in model.named_parameters() if p.grad is None]
+        assert not missing, missing
+        bad = [k for k, p in model.named_parameters() if not torch.isfinite(p.grad).all()]
+        assert not bad, bad
+        opt.step()
+        losses.append(float(loss))
+    assert all(l == l and l < 1e4 for l in losses)
+    assert losses[-1] < losses[0], losses  # same batch three times: SGD must reduce the loss
+    # BatchNorm running statistics moved (training mode) and stay finite
+    bn = getattr(model.point_transformer.conv_input, "1")
+    assert int(bn.num_batches_tracked) == 3 and torch.isfinite(bn.running_var).all()
+
+
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--scenes", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "points/s" and d["value"] > 0 and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches"] == 20 and d["attention_roofline"]["layers"] == sum(refcfg.DEPTHS)
+    assert d["fwd_only"]["value"] > d["value"]

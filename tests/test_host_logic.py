@@ -66,12 +66,22 @@ def test_state_dict_contract(golden_dir, cyl):
     assert abs(sum(p.numel() for p in model.parameters()) - 32.93e6) < 0.05e6
 
 
-def test_unsupported_configs_are_refused():
+def test_multi_sweep_image_fusion_state_dict_contract(golden_dir):
+    """configs/waymo_multi_sweeps.yaml + USE_IMAGE_FEATURE: same keys/shapes as the reference model."""
     from openseg3d_amd import config, segformer
     cfg = config.default_cfg()
     cfg.DATASET.USE_MULTI_SWEEPS = True
-    with pytest.raises(NotImplementedError):
-        segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    cfg.DATASET.USE_IMAGE_FEATURE = True
+    model = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    keys = json.load(open(os.path.join(golden_dir, "segformer_ms_keys.json")))
+    sd = model.state_dict()
+    assert set(sd) == set(keys)
+    assert all(list(sd[k].shape) == list(keys[k]) for k in keys)
+    assert sd["point_transformer.conv_input.0.weight"].shape[-1] == 6  # raw point rows feed the voxel encoder
+
+
+def test_unsupported_configs_are_refused():
+    from openseg3d_amd import config, segformer
     cfg = config.default_cfg()
     cfg.MODEL.SEGMENTOR = "spnet"
     with pytest.raises(NotImplementedError):

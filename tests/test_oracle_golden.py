@@ -105,3 +105,35 @@ def test_segformer_matches_reference_model_code(golden_dir, tag, rng, vs, dp):
     for k in ("point_out", "voxel_out", "aux_voxel_out"):
         assert float((res[k] - torch.from_numpy(d[k])).abs().max()) <= 1e-4, k
     assert np.array_equal(res["aux_voxel_coords"].numpy(), d["aux_voxel_coords"])
+
+
+def test_segformer_multi_sweep_fusion_matches_reference_model_code(golden_dir):
+    """Multi-sweep + image-feature fusion (DeepFusionBlock over knn_query) vs the reference's own model code."""
+    keys = json.load(open(os.path.join(golden_dir, "segformer_ms_keys.json")))
+    d = np.load(os.path.join(golden_dir, "segformer_ms.npz"))
+    p = params.state_dict_for(keys, 0)
+    batch = {k: torch.from_numpy(d[k]) for k in ("points", "voxel_coords", "point_voxel_ids", "point_id_offset",
+                                                  "point_image_features")}
+    batch["batch_size"] = int(d["batch_size"])
+    cfg = {"grid_size": index_ops.grid_size_of(refcfg.CART_VOXEL, refcfg.CART_RANGE), "batching_info": refcfg.BATCHING_INFO,
+           "window_shape": refcfg.WINDOW_SHAPE, "depths": refcfg.DEPTHS, "use_multi_sweeps": True,
+           "use_image_feature": True}
+    with torch.no_grad():
+        res = model.segformer_forward(batch, p, cfg)
+    for k in ("point_out", "voxel_out", "aux_voxel_out"):
+        assert float((res[k] - torch.from_numpy(d[k])).abs().max()) <= 1e-4, k
+
+
+def test_knn_oracle_semantics():
+    from oracle.knn import knn_query
+    xyz = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 2, 0], [5, 5, 5], [5, 5, 6], [1, 0, 0]])
+    off = torch.tensor([3, 6], dtype=torch.int32)
+    idx, dist = knn_query(2, xyz, xyz, off, off)
+    assert idx.tolist() == [[0, 1], [1, 0], [2, 0], [3, 4], [4, 3], [5, 3]]
+    assert torch.allclose(dist[5], torch.tensor([0.0, (16 + 25 + 25) ** 0.5]))
+    idx4, dist4 = knn_query(4, xyz, xyz, off, off)  # k > segment size: unfilled slots = (segment start, 1e5)
+    assert idx4[0].tolist() == [0, 1, 2, 0] and float(dist4[0, 3]) == pytest.approx(1e5)
+    # exact ties are ordered by candidate index
+    t = torch.tensor([[0., 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0]])
+    o = torch.tensor([4], dtype=torch.int32)
+    assert knn_query(4, t, t, o, o)[0][0].tolist() == [0, 1, 2, 3]
