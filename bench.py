@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--mode", choices=["fwd", "fwdbwd"], default="fwdbwd")
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
     ap.add_argument("--batch", type=int, default=1, help="scenes per step per GPU")
+    ap.add_argument("--workload", choices=["one_sweep", "cylinder", "multi_sweeps"], default="one_sweep",
+                    help="one_sweep = BASELINE configs[1] (the headline); cylinder = configs[2] geometry "
+                         "(waymo_one_sweep_cylinder.yaml, use --batch 4); multi_sweeps = configs[3] "
+                         "(waymo_multi_sweeps.yaml + image features, 3 sweeps, use --batch 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU-baseline sample (0 = whole scene)")
     return ap.parse_args()
@@ -178,17 +182,35 @@ def main():
     from openseg3d_amd import batch as B, config, dist as D, scene, segformer
     dev = torch.device("cuda", local)
     cfg = config.default_cfg()  # == configs/waymo_one_sweep.yaml for every key the model path reads
+    if args.workload == "cylinder":  # configs/waymo_one_sweep_cylinder.yaml:2-4
+        cfg.DATASET.USE_CYLINDER = True
+        cfg.DATASET.POINT_CLOUD_RANGE = [0, -3.1415926, -2, 75.2, 3.1415926, 5.2]
+        cfg.DATASET.VOXEL_SIZE = [0.05, 0.012, 0.1]
+    elif args.workload == "multi_sweeps":  # configs/waymo_multi_sweeps.yaml:1-4 + USE_IMAGE_FEATURE
+        cfg.DATASET.USE_MULTI_SWEEPS = True
+        cfg.DATASET.USE_IMAGE_FEATURE = True
     ds = config.DatasetSpec(cfg)
     torch.manual_seed(0)
     model = segformer.build_segmentor(cfg, ds).to(dev)
 
     # resident synthetic scenes: seeds differ per rank (data-parallel shards of the scene stream)
     seeds = [rank * args.scenes * args.batch + i for i in range(args.scenes * args.batch)]
-    scenes_np = [scene.make_scene(s) for s in seeds]
-    groups = [scenes_np[i * args.batch:(i + 1) * args.batch] for i in range(args.scenes)]
-    resident = [B.collate_points(g, dev) for g in groups]
-    offsets = [np.cumsum([s.shape[0] for s in g]).tolist() for g in groups]
-    pts_per_step = [int(r.shape[0]) for r in resident]
+    if args.workload == "multi_sweeps":
+        made = [scene.make_multi_sweep_scene(s, cfg.DATASET.NUM_SWEEPS) for s in seeds]
+        scenes_np, n_cur = [m[0] for m in made], [m[1] for m in made]
+    else:
+        scenes_np = [scene.make_scene(s) for s in seeds]
+        if args.workload == "cylinder":
+            scenes_np = [scene.cart2polar_rows(s) for s in scenes_np]
+        n_cur = [s.shape[0] for s in scenes_np]
+    groups = [list(range(i * args.batch, (i + 1) * args.batch)) for i in range(args.scenes)]
+    resident = [B.collate_points([scenes_np[j] for j in g], dev) for g in groups]
+    offsets = [np.cumsum([n_cur[j] for j in g]).tolist() for g in groups]  # cumulative current-sweep rows
+    images = [None] * len(groups)
+    if args.workload == "multi_sweeps":
+        images = [torch.from_numpy(np.concatenate([scene.make_image_features(seeds[j], n_cur[j]) for j in g])).to(dev)
+                  for g in groups]
+    pts_per_step = [int(o[-1]) for o in offsets]  # points that receive logits
 
     train = args.mode == "fwdbwd"
     opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)  # configs/waymo_one_sweep.yaml
@@ -201,13 +223,13 @@ def main():
 
     def fwd_step(i):
         j = i % len(resident)
-        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range)
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
         with torch.no_grad():
             return model(b)
 
     def train_step(i):
         j = i % len(resident)
-        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range)
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
         opt.zero_grad(set_to_none=True)
         res = net(b)
         vox_lab = labels[j][:1].expand(res["voxel_out"].shape[0])  # constant voxel labels: loss plumbing only
@@ -240,15 +262,18 @@ def main():
     out = None
     if rank == 0:
         model.eval()
-        b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range)
+        b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0])
         roof, per_layer = conv_roofline(model, b0, dev)
         out = {
             "metric": "points/sec fwd+bwd, Waymo 1-sweep ~180k pts @0.1m voxel; logit parity",
             "value": round(n_pts / dt, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "waymo_one_sweep (BASELINE configs[1]): synthetic 64-beam scene, "
-                                   f"{pts_per_step[0]} pts/step/GPU, voxel 0.1 m, grid 1440x1440x64, "
+            "config": {"workload": {"one_sweep": "waymo_one_sweep (BASELINE configs[1])",
+                                    "cylinder": "waymo_one_sweep_cylinder (BASELINE configs[2] geometry)",
+                                    "multi_sweeps": "waymo_multi_sweeps + image features (BASELINE configs[3], 3 sweeps)"
+                                    }[args.workload] + ": synthetic 64-beam scene, "
+                                   f"{pts_per_step[0]} pts/step/GPU, voxel {ds.voxel_size}, grid {ds.grid_size.tolist()}, "
                                    f"{'forward-only eval' if not train else 'fwd+loss+bwd+SGD step'}",
                        "mode": args.mode, "scenes_per_step_per_gpu": args.batch,
                        "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}"},

@@ -18,10 +18,14 @@ def collate_points(samples, device):
     return pts.to(device=device)
 
 
-def batch_from_resident(points, row_offsets, voxel_size, point_cloud_range):
-    """points: collated [sum N, 1+D] tensor already in HBM; row_offsets: cumulative rows per sample (ints)."""
+def batch_from_resident(points, row_offsets, voxel_size, point_cloud_range, image_features=None):
+    """points: collated [sum N, 1+D] tensor already in HBM; row_offsets: cumulative rows per sample (ints) --
+    for multi-sweep batches the cumulative CURRENT-sweep rows (collate_batch's cur_point_count,
+    waymo_dataset.py:367-373); image_features: optional [sum N_current, 28] tensor."""
     coords, ids = ops.voxelize(points, voxel_size, point_cloud_range, xyz_col=1, batch_col=0)
+    extra = {} if image_features is None else {"point_image_features": image_features}
     return {
+        **extra,
         "points": points if points.dtype == torch.float32 else points.float(),
         "voxel_coords": coords.float(),
         "point_voxel_ids": ids.long(),

@@ -83,3 +83,30 @@ def make_small_scene(seed, n_points, extent=12.0, dtype=np.float32):
     n = xyz.shape[0]
     feat = np.stack([np.zeros(n), np.tanh(rs.uniform(0, 1, size=n)), rs.uniform(0, 1, size=n)], axis=1)
     return np.concatenate([xyz, feat], axis=1).astype(dtype)
+
+
+def make_multi_sweep_scene(seed, n_sweeps=3, dtype=np.float32):
+    """Current sweep + (n_sweeps - 1) history sweeps re-posed by a small ego motion, time lag in column 3
+    (waymo_dataset.py:156-202 merges sweeps this way; configs/waymo_multi_sweeps.yaml NUM_SWEEPS = 3).
+    Returns (rows [N, 6], n_current): current-sweep rows come first and have time lag exactly 0."""
+    rs = np.random.RandomState(9000 + int(seed))
+    cur = make_scene(seed, dtype=np.float64)
+    sweeps = [cur]
+    for i in range(1, n_sweeps):
+        hist = make_scene(seed, n_side=6000, dtype=np.float64)
+        yaw = rs.normal(0.0, 0.01) * i
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        xy = hist[:, :2] @ np.array([[c, -s_], [s_, c]]) + np.array([0.6 * i, rs.normal(0, 0.05)])
+        hist[:, :2] = xy
+        hist[:, :3] += rs.normal(0.0, 0.01, size=(hist.shape[0], 3))
+        hist[:, 3] = 0.1 * i
+        sweeps.append(hist)
+    return np.concatenate(sweeps, axis=0).astype(dtype), cur.shape[0]
+
+
+def make_image_features(seed, n_points, dim=28, hit_ratio=0.5, dtype=np.float32):
+    """Per-point image features of tools/extract_image_feature.py shape: zero rows where no camera sees the point."""
+    rs = np.random.RandomState(12000 + int(seed))
+    f = rs.randn(n_points, dim).astype(dtype)
+    f[rs.rand(n_points) >= hit_ratio] = 0
+    return f
