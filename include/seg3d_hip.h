@@ -146,7 +146,7 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
  * Same split-bf16 tall-skinny kernel as the sparse wgrad (rows = MFMA K dimension); the forward and the
  * input-gradient GEMMs stay on rocBLAS/hipBLASLt.  cin, cout multiples of 4. */
 int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
-                       void* stream);
+                       float* db /* [cout] bias gradient = column sums of dy, or NULL */, void* stream);
 /* a6, a22  forward / input gradient of the same layers: y[m, cout] = x[m, cin] . W^T + bias, as the
  * single-offset case of the split-bf16 gather-GEMM kernel (W fragments staged through LDS once per
  * 128-row tile).  weight is torch's [cout, cin]; transpose=1 packs W itself as the operand, i.e.

@@ -27,7 +27,8 @@ constexpr int kThreads = kWaves * 64;
 template <bool SPARSE>
 __global__ __launch_bounds__(kThreads) void wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                const int32_t* __restrict__ nbr, int64_t m_rows, int cin,
-                                                               int cout, int rows_per_wave, int kk, float* __restrict__ dw) {
+                                                               int cout, int rows_per_wave, int kk, float* __restrict__ dw,
+                                                               float* __restrict__ db) {
     // per wave: operand images 2 x [2 hi/lo][4 row groups][64 records] x 16 B = 16 KiB, pair queue 1 KiB
     __shared__ __attribute__((aligned(16))) uint4 img[kWaves][2][2][4][64];
     __shared__ int32_t q_in[kWaves][128];
@@ -54,6 +55,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_split_kernel(const float* __re
         for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4(*my)[2][4][64] = img[wave];  // [operand][hi/lo][row group][record]
+    // bias gradient (dense layers): column sums of dy, taken by the waves of the first ci block only
+    const bool want_db = !SPARSE && db != nullptr && bi == 0;
+    f32x4 db_acc = {0.f, 0.f, 0.f, 0.f};
 
     // one 32-pair step: rows come from (in_of(e), out_of(e)), e = 0..31; entries >= valid are zero
     auto step = [&](auto in_of, auto out_of, int valid) {
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_split_kernel(const float* __re
             const f32x4 ly = *reinterpret_cast<const f32x4*>(dy + ro * cout + (a_ok ? co0 + 4 * cq : 0));
             xa[i] = ok && b_ok ? lx : z;
             ya[i] = ok && a_ok ? ly : z;
+            if (want_db) db_acc += ya[i];
         }
         // transpose in registers: channel j of this lane's quad, 8 rows -> one 16-B record
 #pragma unroll
@@ -138,6 +143,15 @@ __global__ __launch_bounds__(kThreads) void wgrad_split_kernel(const float* __re
         }
     }
 
+    if (want_db) {  // lanes cq, cq+16, cq+32, cq+48 hold the four row groups of the same channel quad
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = db_acc[j];
+            v += __shfl_xor(v, 16, SEG3D_WAVE);
+            v += __shfl_xor(v, 32, SEG3D_WAVE);
+            if (rg == 0 && a_ok && v != 0.0f) atomicAdd(&db[co0 + 4 * cq + j], v);
+        }
+    }
     // ---- epilogue: D[a][b][r] = dw[co = co0 + 4*(4g + r) + a][ci = ci0 + 4*c16 + b]; stage [co_local][ci_local]
     float* st = reinterpret_cast<float*>(&my[0][0][0][0]);  // 16 KiB = 64 x 64 floats
 #pragma unroll
@@ -159,7 +173,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_split_kernel(const float* __re
 }
 
 template <bool SPARSE>
-int dispatch(const float* x, const float* dy, const int32_t* nbr, int64_t m, int cin, int cout, float* dw, hipStream_t st) {
+int dispatch(const float* x, const float* dy, const int32_t* nbr, int64_t m, int cin, int cout, float* dw, float* db,
+             hipStream_t st) {
     const int nblk = ((cin + 63) / 64) * ((cout + 63) / 64);
     const int blocks = nblk * (SPARSE ? 27 : 1);
     // aim for ~8k waves in flight; chunks are multiples of 64 rows
@@ -169,7 +184,7 @@ int dispatch(const float* x, const float* dy, const int32_t* nbr, int64_t m, int
     if (rows > 4096) rows = 4096;
     dim3 grid((unsigned)ceil_div64(m, rows * kWaves), SPARSE ? 27 : 1, (unsigned)nblk);
     hipLaunchKernelGGL(wgrad_split_kernel<SPARSE>, grid, dim3(kThreads), 0, st, x, dy, nbr, m, cin, cout, (int)rows,
-                       SPARSE ? 27 : 1, dw);
+                       SPARSE ? 27 : 1, dw, db);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -179,15 +194,16 @@ int dispatch(const float* x, const float* dy, const int32_t* nbr, int64_t m, int
 // used by seg3d_spconv_wgrad (spconv.hip)
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
                        hipStream_t st) {
-    return dispatch<true>(x, dy, nbr, m_out, cin, cout, dw, st);
+    return dispatch<true>(x, dy, nbr, m_out, cin, cout, dw, nullptr, st);
 }
 
 extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
-                                  void* stream) {
+                                  float* db, void* stream) {
     if (m < 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || !dw) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(dw, 0, (size_t)cin * cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
+    if (db && hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
     if (m == 0) return SEG3D_OK;
     if (!x || !dy) return SEG3D_EINVAL;
-    return dispatch<false>(x, dy, nullptr, m, cin, cout, dw, st);
+    return dispatch<false>(x, dy, nullptr, m, cin, cout, dw, db, st);
 }

@@ -298,10 +298,13 @@ class _LinearFn(torch.autograd.Function):
                 dx = _linear_apply(dy, _linear_pack(weight, 1), None, cout, cin)
             else:
                 dx = dy @ weight
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _stream())
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:  # column sums of dy ride along with the weight-gradient pass
+                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _stream())
+        elif want_db:
             db = dy.sum(0)
         return dx, dw, db, None
 
