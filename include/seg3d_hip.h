@@ -143,10 +143,12 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
 
 /* a6, a22  weight gradient of the dense per-point / per-voxel Linear layers (segformer.py:21-32,58-76,
  * point_transformer_layer.py:260-276, cosine_msa.py:58-63,403):  dw[cout][cin] = dy^T . x  over m rows.
- * Same split-bf16 tall-skinny kernel as the sparse wgrad (rows = MFMA K dimension); the forward and the
- * input-gradient GEMMs stay on rocBLAS/hipBLASLt.  cin, cout multiples of 4. */
+ * Split-bf16 tall-skinny GEMM (rows = MFMA K dimension), workgroup-tiled; partial blocks per row chunk go to
+ * the workspace and are summed in a fixed order, so dw/db are bit-reproducible and need no memset.
+ * db (nullable) receives the bias gradient = column sums of dy.  cin, cout multiples of 4. */
+size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int32_t cout);
 int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
-                       float* db /* [cout] bias gradient = column sums of dy, or NULL */, void* stream);
+                       float* db /* [cout] or NULL */, void* workspace, size_t workspace_bytes, void* stream);
 /* a6, a22  forward / input gradient of the same layers: y[m, cout] = x[m, cin] . W^T + bias, as the
  * single-offset case of the split-bf16 gather-GEMM kernel (W fragments staged through LDS once per
  * 128-row tile).  weight is torch's [cout, cin]; transpose=1 packs W itself as the operand, i.e.

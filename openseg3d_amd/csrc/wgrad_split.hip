@@ -1,4 +1,5 @@
-// Weight gradients in split-bf16 arithmetic: sparse conv (a9-a11 wgrad) and dense Linear (a6/a22 wgrad).
+// Weight gradients in split-bf16 arithmetic: sparse conv (a9-a11 wgrad); the dense Linear case of the same
+// kernel body (SPARSE = false) is superseded by wgrad_dense.hip and no longer instantiated.
 //   sparse:  dw[co][k][ci] = sum_r x[nbr[k][r]][ci] * dy[r][co]
 //   dense :  dw[co][ci]    = sum_r x[r][ci]         * dy[r][co]
 // Both are "tall-skinny" GEMMs: tiny outputs (C x C), reduction over 1e4..1e5 rows.  rocBLAS/hipBLASLt picks
@@ -195,15 +196,4 @@ int dispatch(const float* x, const float* dy, const int32_t* nbr, int64_t m, int
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
                        hipStream_t st) {
     return dispatch<true>(x, dy, nbr, m_out, cin, cout, dw, nullptr, st);
-}
-
-extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
-                                  float* db, void* stream) {
-    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || !dw) return SEG3D_EINVAL;
-    hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(dw, 0, (size_t)cin * cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (db && hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (m == 0) return SEG3D_OK;
-    if (!x || !dy) return SEG3D_EINVAL;
-    return dispatch<false>(x, dy, nullptr, m, cin, cout, dw, db, st);
 }

@@ -303,7 +303,10 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             if want_db:  # column sums of dy ride along with the weight-gradient pass
                 db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
-            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _stream())
+            ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
+            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws),
+                      ws_bytes, _stream())
         elif want_db:
             db = dy.sum(0)
         return dx, dw, db, None

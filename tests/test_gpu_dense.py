@@ -29,6 +29,29 @@ def test_linear_wgrad_matches_autograd(m, cin, cout):
     assert float((bg.grad.cpu().double() - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
 
 
+def test_linear_wgrad_is_reproducible_and_handles_tiny_inputs():
+    """Partial blocks are summed in a fixed order: two runs give the same bits.  m = 1 and m = 0 are legal."""
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    x = torch.randn(33333, 96, device=dev)
+    w = torch.randn(288, 96, device=dev)
+    b = torch.randn(288, device=dev)
+    g = torch.randn(33333, 288, device=dev)
+    grads = []
+    for _ in range(2):
+        wg, bg = w.clone().requires_grad_(), b.clone().requires_grad_()
+        ops.linear(x, wg, bg).backward(g)
+        grads.append((wg.grad.clone(), bg.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    for m in (1, 0):
+        wg, bg = w.clone().requires_grad_(), b.clone().requires_grad_()
+        ops.linear(x[:m], wg, bg).backward(g[:m])
+        ref_w = g[:m].double().t() @ x[:m].double()
+        assert float((wg.grad.double() - ref_w).abs().max()) < 1e-4
+        assert float((bg.grad.double() - g[:m].double().sum(0)).abs().max()) < 1e-5
+
+
 def test_linear_falls_back_for_unsupported_shapes():
     from openseg3d_amd import ops
     dev = torch.device("cuda:0")
