@@ -1,248 +1,214 @@
-// Dense Linear weight gradient (a6/a22 wgrad) in split-bf16 arithmetic, workgroup-tiled and deterministic:
+// Dense Linear weight gradient (a6/a22 wgrad) in split-bf16 arithmetic, deterministic:
 //   dw[co][ci] = sum_r dy[r][co] * x[r][ci],   db[co] = sum_r dy[r][co]
 // A tall-skinny GEMM: outputs of C x C (48..768), reduction over 1e4..2e5 rows; the row index is the MFMA K
 // dimension of v_mfma_f32_16x16x32_bf16.
 //
-// A workgroup of WA x WB waves owns a (64*WA) x (64*WB) block of dw over one chunk of rows; wave (wa, wb)
-// accumulates the 64 x 64 sub-block in 16 accumulator tiles.  Per 32-row step the workgroup stages WA slabs of
-// dy and WB slabs of x (a slab = 32 rows x 64 channels): the wave that owns a slab loads 8 rows x 4 channels
-// per lane (16-B loads along the channel axis), converts to bf16 hi/lo and packs the 8 rows of one channel into
-// one 16-B record -- the transpose happens in registers -- and writes the records to a double-buffered LDS
-// image [slab][hi|lo][row group][64 records]; every wave then reads its A (dy) and B (x) fragments with
-// conflict-free 16-B reads and issues 16*3 MFMAs.  The loads of step s+1 are issued before the MFMAs of step
-// s, so global latency hides behind the matrix pipe; one __syncthreads per step.
-// Each operand row is read (64*WA + 64*WB) / (64*WA * 64*WB) times per output column instead of 1/32: the
-// (WA, WB) shape is picked per layer to minimise MFMA padding + operand traffic (plan()).
-// Channel c of a slab sits in record (c%4)*16 + c/4, so MFMA tile t holds channels {4*i + t}.
+// A workgroup of 4 waves owns one 64 x 64 block of dw (co x ci, masked at the edges) over one chunk of rows; its
+// waves take the 32-row steps of the chunk round-robin (split-K inside the workgroup) and each accumulates the
+// whole block in 16 accumulator tiles.  Operands go from global memory straight into MFMA fragments: lane
+// (cq, rg) loads rows 8*rg .. 8*rg+7 of channels 4*cq .. 4*cq+3 with 16-B loads, so for channel j of its quad
+// it holds exactly the 8 consecutive K (row) values the MFMA wants from lane (c16 = cq, g = rg) of tile j --
+// tile t holds channels {4*i + t}.  No LDS and no barrier in the main loop; the loads of the wave's next step
+// are issued as soon as the registers they land in have been converted, and 8+ independent waves per CU cover
+// the rest.
 //
-// No atomics: every (row chunk, block) writes its partial block to a workspace with plain stores and a second
-// kernel sums the chunks in a fixed order -- the gradient is bit-reproducible run to run, and neither dw nor
-// db needs a memset.  gridDim.x is padded to a multiple of 8 so that the blocks sharing a row chunk land
-// on the same XCD (round-robin dispatch) and share its L2.
+// No atomics: the four accumulators of a workgroup are summed through LDS in wave order, every (row chunk,
+// block) writes its partial to a workspace with plain stores and a second kernel sums the chunks in a fixed
+// order -- the gradient is bit-reproducible run to run, and neither dw nor db needs a memset.
+// Block order: id -> (xcd = id % 8, k = id / 8), chunk = 8 * (k / tiles) + xcd, block = k % tiles, so the
+// workgroups that read the same rows (all blocks of a chunk) are dispatched back to back on the same XCD
+// and share its L2.
+#include <cstdlib>
+#include <type_traits>
+
 #include "attn_common.hpp"
 
 namespace {
 
 using namespace attn;
 
+constexpr int kWaves = 4;
+constexpr int kThreads = 64 * kWaves;
+
 struct Plan {
-    int wa, wb;      // waves along cout / cin
-    int nbo, nbi;    // blocks along cout / cin
-    int chunks;      // row chunks (partial sums)
-    int64_t rows;    // rows per chunk (multiple of 32)
+    int nbo, nbi;  // 64-channel blocks along cout / cin
+    int chunks;    // row chunks (partial sums)
+    int64_t rows;  // rows per chunk (multiple of 32)
 };
 
 Plan plan(int64_t m, int cin, int cout) {
-    static const int shapes[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 6}, {2, 1}, {2, 2}, {2, 3}, {2, 4},
-                                    {3, 1}, {3, 2}, {4, 1}, {4, 2}, {6, 1}};
-    Plan best{};
-    double best_cost = 1e30;
-    for (const auto& s : shapes) {
-        const int wa = s[0], wb = s[1];
-        const int nbo = (cout + 64 * wa - 1) / (64 * wa), nbi = (cin + 64 * wb - 1) / (64 * wb);
-        // per 32-row step on one CU: MFMA cycles (48 MFMAs x 16 cycles per wave tile, 4 SIMDs) + operand fetch
-        // cycles (64 B/clk per CU), counted without overlap
-        const double mfma = (double)nbo * wa * nbi * wb * 768.0 / 4.0;
-        const double mem = (double)nbo * nbi * (wa + wb) * 64.0 * 32.0 * 4.0 / 64.0;
-        const double cost = mfma + mem;
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            best = Plan{wa, wb, nbo, nbi, 0, 0};
-        }
-    }
-    // one resident workgroup per CU when the partial blocks are large (their write + re-read is the overhead
-    // that grows with the chunk count), two when they are small; chunks of at least 256 rows
-    const int tiles = best.nbo * best.nbi;
-    const int target = (int64_t)cin * cout >= 65536 ? 256 : 512;
-    int64_t chunks = (target + tiles - 1) / tiles;
-    if (chunks < 1) chunks = 1;
-    int64_t rows = m > 0 ? (m + chunks - 1) / chunks : 32;
-    if (rows < 256) rows = 256;
+    Plan p{(cout + 63) / 64, (cin + 63) / 64, 0, 32};
+    if (m <= 0) return p;
+    const int tiles = p.nbo * p.nbi;
+    // 2 waves per SIMD = 2 workgroups per CU = 512 resident workgroups.  Few blocks per chunk: one resident
+    // round of long chunks (per-workgroup prologue / reduction overhead matters); many blocks per chunk: two
+    // rounds.  Chunks map to XCDs round-robin, so their number is kept a multiple of 8.
+    int target = tiles >= 16 ? 1024 : 512;
+    if (const char* e = getenv("SEG3D_WGRAD_TARGET")) target = atoi(e);
+    int64_t chunks = target / tiles / 8 * 8;
+    if (chunks < 8) chunks = 8;
+    int64_t rows = (m + chunks - 1) / chunks;
+    if (rows < 32 * kWaves * 4) rows = 32 * kWaves * 4;
     rows = (rows + 31) / 32 * 32;
-    best.rows = rows;
-    best.chunks = m > 0 ? (int)((m + rows - 1) / rows) : 0;
-    return best;
+    p.rows = rows;
+    p.chunks = (int)((m + rows - 1) / rows);
+    return p;
 }
 
-template <int WA, int WB>
-__global__ __launch_bounds__(64 * WA * WB) void wgrad_dense_kernel(const float* __restrict__ x,
-                                                                    const float* __restrict__ dy, int64_t m_rows,
-                                                                    int cin, int cout, int rows_per_chunk, int nbi,
-                                                                    float* __restrict__ part_w,
-                                                                    float* __restrict__ part_b) {
-    constexpr int NW = WA * WB, NS = WA + WB, ITEMS = (NS + NW - 1) / NW;
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // [2 buffers][NS slabs][2 hi/lo][4 row groups][64]
+__global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               int64_t m_rows, int cin, int cout, int rows_per_chunk,
+                                                               int nbi, int tiles, float* __restrict__ part,
+                                                               int want_bias) {
+    __shared__ __attribute__((aligned(16))) float red[64 * 64];  // block sum [co_local][ci_local]
+    __shared__ float red_b[kWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cq = lane & 15, rg = lane >> 4;  // load role: channel quad, row group (8 rows); MFMA role: c16, g
-    const int wa = wave / WB, wb = wave % WB;
-    const int bi = blockIdx.y % nbi, bo = blockIdx.y / nbi;
-    const int ci0 = bi * 64 * WB, co0 = bo * 64 * WA;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_chunk;
-    if (r_begin >= m_rows) return;  // padding blocks of the XCD-aligned grid (whole workgroup)
+    const int cq = lane & 15, rg = lane >> 4;  // channel quad, row group: load role == MFMA role (c16, g)
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int chunk = (k / tiles) * 8 + xcd, tile = k % tiles;
+    const int bi = tile % nbi, bo = tile / nbi;
+    const int ci0 = bi * 64, co0 = bo * 64;
+    const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
+    if (r_begin >= m_rows) return;  // padding of the XCD-aligned grid (whole workgroup)
     const int64_t r_end = r_begin + rows_per_chunk < m_rows ? r_begin + rows_per_chunk : m_rows;
-    const int n_steps = (int)((r_end - r_begin + 31) / 32);
-
-    auto image = [&](int buf, int slab, int hl, int row_group) -> uint4* {
-        return lds + ((((buf * NS + slab) * 2 + hl) * 4 + row_group) * 64);
-    };
-
-    // slabs this wave stages: slab < WA is dy channels co0 + 64*slab.., otherwise x channels ci0 + 64*(slab-WA)..
-    const float* src[ITEMS];
-    int ld[ITEMS];
-    bool has[ITEMS], ch_ok[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int s = wave + it * NW;
-        has[it] = s < NS;
-        const bool is_dy = s < WA;
-        const int c = is_dy ? co0 + 64 * s + 4 * cq : ci0 + 64 * (s - WA) + 4 * cq;
-        ld[it] = is_dy ? cout : cin;
-        ch_ok[it] = has[it] && c < ld[it];
-        src[it] = (is_dy ? dy : x) + (ch_ok[it] ? c : 0);
-    }
-    const bool want_db = part_b != nullptr && bi == 0 && wave < WA;  // dy slabs are always item 0 of waves < WA
-    f32x4 db_acc = {0.f, 0.f, 0.f, 0.f};
-
-    f32x4 pre[ITEMS][8];
-    auto fetch = [&](int step) {
-        const int64_t r0 = r_begin + 32 * (int64_t)step + 8 * rg;
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            if (!has[it]) continue;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int64_t r = r0 + i;
-                const bool ok = r < r_end && ch_ok[it];
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src[it] + (ok ? r : r_begin) * ld[it]);
-                pre[it][i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            if (!has[it]) continue;
-            const int s = wave + it * NW;
-            if (it == 0 && want_db) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) db_acc += pre[0][i];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = pre[it][i][j];
-                bf16x8 hi, lo;
-                split_frag(v, &hi, &lo);
-                image(buf, s, 0, rg)[j * 16 + cq] = __builtin_bit_cast(uint4, hi);
-                image(buf, s, 1, rg)[j * 16 + cq] = __builtin_bit_cast(uint4, lo);
-            }
-        }
-    };
+    // Channel quads past cin / cout read quad 0 instead: they only feed output rows / columns that are never
+    // stored, so no masking is needed.  Lane offsets are 32-bit and added to a wave-uniform row pointer.
+    const bool a_ok = co0 + 4 * cq < cout, b_ok = ci0 + 4 * cq < cin;
+    const uint32_t yoff = (uint32_t)((8 * rg * cout + (a_ok ? co0 + 4 * cq : 0)) * 4);
+    const uint32_t xoff = (uint32_t)((8 * rg * cin + (b_ok ? ci0 + 4 * cq : 0)) * 4);
+    const bool want_db = want_bias && bi == 0;
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 db_acc = {0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int step = 0; step < n_steps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < n_steps;
-        if (more) fetch(step + 1);
-        bf16x8 b_hi[4], b_lo[4];
+    f32x4 xr[8], yr[8];
+    bf16x8 b_hi[4], b_lo[4];
+    auto load_rows = [&](const float* src, int ld, uint32_t off, int step, f32x4(&dst)[8]) {
+        const char* base = reinterpret_cast<const char*>(src + (r_begin + 32 * (int64_t)step) * ld);  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)i * ld * 4 + off);
+    };
+    auto make_b = [&]() {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            b_hi[b] = __builtin_bit_cast(bf16x8, image(buf, WA + wb, 0, rg)[b * 16 + cq]);
-            b_lo[b] = __builtin_bit_cast(bf16x8, image(buf, WA + wb, 1, rg)[b * 16 + cq]);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = xr[i][b];
+            split_frag(v, &b_hi[b], &b_lo[b]);
+        }
+    };
+    auto multiply = [&]() {
+        if (want_db) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) db_acc += yr[i];
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const bf16x8 a_hi = __builtin_bit_cast(bf16x8, image(buf, wa, 0, rg)[a * 16 + cq]);
-            const bf16x8 a_lo = __builtin_bit_cast(bf16x8, image(buf, wa, 1, rg)[a * 16 + cq]);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = yr[i][a];
+            bf16x8 a_hi, a_lo;
+            split_frag(v, &a_hi, &a_lo);
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
         }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
+    };
+    // full 32-row steps: the x rows of the wave's next step are requested as soon as this step's are converted,
+    // its dy rows right after their last use
+    const int n_full = (int)((r_end - r_begin) / 32);
+    int s = wave;
+    if (s < n_full) {
+        load_rows(x, cin, xoff, s, xr);
+        load_rows(dy, cout, yoff, s, yr);
+    }
+    for (; s < n_full; s += kWaves) {
+        const bool more = s + kWaves < n_full;
+        make_b();
+        if (more) load_rows(x, cin, xoff, s + kWaves, xr);
+        multiply();
+        if (more) load_rows(dy, cout, yoff, s + kWaves, yr);
+    }
+    // the chunk's last, partial step (only the last chunk of the tensor has one): rows clamped and masked
+    if ((r_end - r_begin) % 32 != 0 && n_full % kWaves == wave) {
+        const int64_t r0 = r_begin + 32 * (int64_t)n_full + 8 * rg;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = r0 + i < r_end;
+            const int64_t r = ok ? r0 + i : r_end - 1;
+            const f32x4 vx = *reinterpret_cast<const f32x4*>(x + r * cin + (b_ok ? ci0 + 4 * cq : 0));
+            const f32x4 vy = *reinterpret_cast<const f32x4*>(dy + r * cout + (a_ok ? co0 + 4 * cq : 0));
+            xr[i] = ok ? vx : z;
+            yr[i] = ok ? vy : z;
+        }
+        make_b();
+        multiply();
     }
 
-    const int64_t chunk = blockIdx.x;
+    // ---- sum the waves' blocks in wave order: acc[a][b][r] = dw[co = 4*(4g + r) + a][ci = 4*c16 + b]
+    for (int w = 0; w < kWaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4* slot = reinterpret_cast<f32x4*>(&red[(4 * (4 * rg + r) + a) * 64 + 4 * cq]);
+                    f32x4 v = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+                    if (w > 0) v += *slot;
+                    *slot = v;
+                }
+        }
+        __syncthreads();
+    }
+    // partial of this chunk: [cout][cin] block sums followed by [cout] column sums of dy
+    float* pw = part + (int64_t)chunk * ((int64_t)cout * cin + cout);
+    for (int e = threadIdx.x; e < 64 * 16; e += kThreads) {
+        const int row = e >> 4, q = e & 15;
+        const int co = co0 + row, ci = ci0 + 4 * q;
+        if (co < cout && ci < cin)
+            *reinterpret_cast<f32x4*>(pw + (int64_t)co * cin + ci) = *reinterpret_cast<const f32x4*>(&red[row * 64 + 4 * q]);
+    }
     if (want_db) {  // lanes cq, cq+16, cq+32, cq+48 hold the four row groups of the same channel quad
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = db_acc[j];
             v += __shfl_xor(v, 16, SEG3D_WAVE);
             v += __shfl_xor(v, 32, SEG3D_WAVE);
-            const int co = co0 + 64 * wave + 4 * cq + j;
-            if (rg == 0 && co < cout) part_b[chunk * cout + co] = v;
+            if (rg == 0) red_b[wave][4 * cq + j] = v;
         }
-    }
-    // ---- epilogue: acc[a][b][r] = dw[co = 4*(4g + r) + a][ci = 4*c16 + b] of this wave's sub-block; staged in two
-    // halves of 32 output rows through 8 KiB of LDS per wave, stored as whole contiguous rows of the partial
-    float* st = reinterpret_cast<float*>(lds) + wave * 2048;
-    float* pw = part_w + chunk * (int64_t)cout * cin;
-    const int ci = ci0 + 64 * wb + lane;
+        __syncthreads();
+        if (threadIdx.x < 64 && co0 + threadIdx.x < cout) {
+            float t = red_b[0][threadIdx.x];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if ((rg >> 1) == h) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st[(4 * (4 * (rg & 1) + r) + a) * 64 + 4 * cq + b] = acc[a][b][r];
+            for (int w = 1; w < kWaves; ++w) t += red_b[w][threadIdx.x];
+            pw[(int64_t)cout * cin + co0 + threadIdx.x] = t;
         }
-        __builtin_amdgcn_wave_barrier();
-        if (ci < cin) {
-            for (int row = 0; row < 32; ++row) {
-                const int co = co0 + 64 * wa + 32 * h + row;
-                if (co >= cout) break;
-                pw[(int64_t)co * cin + ci] = st[row * 64 + lane];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// out[i] = sum over chunks of part[c][i], fixed order
+// dw[i] / db[i - nw] = sum over chunks of part[c][i] in a fixed order: a workgroup owns 32 columns, its 8 row
+// lanes take chunks q, q+8, .. and are combined through LDS in lane order
 __global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restrict__ part, int chunks, int64_t n,
-                                                          float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = 0;
-    for (; c + 4 <= chunks; c += 4) {
-        s0 += part[(int64_t)c * n + i];
-        s1 += part[(int64_t)(c + 1) * n + i];
-        s2 += part[(int64_t)(c + 2) * n + i];
-        s3 += part[(int64_t)(c + 3) * n + i];
+                                                          int64_t nw, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (i < n)
+        for (int c = q; c < chunks; c += 8) s += part[(int64_t)c * n + i];
+    red[q][col] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][col];
+        if (i < nw) dw[i] = t;
+        else if (db) db[i - nw] = t;
     }
-    for (; c < chunks; ++c) s0 += part[(int64_t)c * n + i];
-    out[i] = (s0 + s1) + (s2 + s3);
-}
-
-template <int WA, int WB>
-int launch(const Plan& p, const float* x, const float* dy, int64_t m, int cin, int cout, float* part_w, float* part_b,
-           hipStream_t st) {
-    constexpr int NS = WA + WB;
-    constexpr size_t lds_bytes = (size_t)2 * NS * 2 * 4 * 64 * sizeof(uint4);
-    static bool configured = false;
-    if (!configured) {
-        if (lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dense_kernel<WA, WB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return SEG3D_ELAUNCH;
-        configured = true;
-    }
-    const unsigned gx = (unsigned)((p.chunks + 7) / 8 * 8);
-    hipLaunchKernelGGL((wgrad_dense_kernel<WA, WB>), dim3(gx, (unsigned)(p.nbo * p.nbi)), dim3(64 * WA * WB), lds_bytes,
-                       st, x, dy, m, cin, cout, (int)p.rows, p.nbi, part_w, part_b);
-    SEG3D_CHECK_LAUNCH();
-    return SEG3D_OK;
 }
 
 }  // namespace
@@ -260,36 +226,18 @@ extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, in
     if (workspace_bytes < seg3d_linear_wgrad_workspace_bytes(m, cin, cout) || (m > 0 && !workspace)) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
     const Plan p = plan(m, cin, cout);
-    float* part_w = static_cast<float*>(workspace);
-    float* part_b = part_w + (size_t)p.chunks * cin * cout;
+    float* part = static_cast<float*>(workspace);
     if (m > 0) {
-        int rc = SEG3D_EINVAL;
-#define SEG3D_WG(A, B) \
-    if (p.wa == A && p.wb == B) rc = launch<A, B>(p, x, dy, m, cin, cout, part_w, db ? part_b : nullptr, st)
-        SEG3D_WG(1, 1);
-        SEG3D_WG(1, 2);
-        SEG3D_WG(1, 3);
-        SEG3D_WG(1, 4);
-        SEG3D_WG(1, 6);
-        SEG3D_WG(2, 1);
-        SEG3D_WG(2, 2);
-        SEG3D_WG(2, 3);
-        SEG3D_WG(2, 4);
-        SEG3D_WG(3, 1);
-        SEG3D_WG(3, 2);
-        SEG3D_WG(4, 1);
-        SEG3D_WG(4, 2);
-        SEG3D_WG(6, 1);
-#undef SEG3D_WG
-        if (rc != SEG3D_OK) return rc;
-    }
-    const int64_t nw = (int64_t)cin * cout;
-    hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(nw, 256)), dim3(256), 0, st, part_w, p.chunks, nw, dw);
-    SEG3D_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(cout, 256)), dim3(256), 0, st, part_b, p.chunks,
-                           (int64_t)cout, db);
+        const int tiles = p.nbo * p.nbi;
+        const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
+        hipLaunchKernelGGL(wgrad_dense_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows, p.nbi,
+                           tiles, part, db ? 1 : 0);
         SEG3D_CHECK_LAUNCH();
     }
+    // without db the trailing [cout] columns of each partial are never written; their sums are discarded
+    const int64_t nw = (int64_t)cin * cout, stride = nw + cout;
+    hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(stride, 32)), dim3(256), 0, st, part, p.chunks, stride,
+                       nw, dw, db);
+    SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

@@ -1,0 +1,33 @@
+"""Time seg3d_linear_wgrad on the Linear shapes of the waymo_one_sweep workload (GPU box only)."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
+import torch
+from openseg3d_amd import _lib, ops
+
+SHAPES = [(121168, 96, 96), (121168, 96, 192), (121168, 192, 96), (58453, 192, 192), (58453, 192, 384),
+          (58453, 384, 192), (19483, 384, 384), (19483, 384, 768), (19483, 768, 384), (6943, 768, 768),
+          (174633, 64, 64), (174633, 64, 128)]
+dev = torch.device("cuda:0")
+for m, cin, cout in SHAPES:
+    x = torch.randn(m, cin, device=dev)
+    dy = torch.randn(m, cout, device=dev)
+    dw = torch.empty(cout, cin, device=dev)
+    db = torch.empty(cout, device=dev)
+    nb = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, cin, cout)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    def run():
+        _lib.call("seg3d_linear_wgrad", ops._ptr(x), ops._ptr(dy), m, cin, cout, ops._ptr(dw), ops._ptr(db), ops._ptr(ws), nb,
+                  ops._stream())
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    gb = m * (cin + cout) * 4 / 1e9
+    print(f"m={m:7d} {cin:4d}->{cout:4d}: {us:7.1f} us  {gb / us * 1e6:7.0f} GB/s algorithmic  ws {nb / 1e6:.1f} MB", flush=True)
