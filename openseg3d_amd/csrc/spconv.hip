@@ -18,8 +18,9 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
                       hipStream_t st);
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
                      int cout, float* y, hipStream_t st);
+size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
-                       hipStream_t st);  // wgrad_split.hip
+                       void* workspace, size_t workspace_bytes, hipStream_t st);
 
 namespace {
 
@@ -310,16 +311,20 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
     return launch_fwd<1>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
 }
 
-size_t seg3d_spconv_wgrad_workspace_bytes(int64_t, int32_t, int32_t) { return 256; }
+size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout) {
+    if (m_out < 0 || cin <= 0 || cout <= 0) return 0;
+    return wgrad_split_sparse_workspace_bytes(m_out, cin, cout);  // the exact-fp32 path needs none
+}
 
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int64_t m_in, int32_t cin,
-                       int32_t cout, int32_t flags, float* dw, void*, size_t, void* stream) {
+                       int32_t cout, int32_t flags, float* dw, void* workspace, size_t workspace_bytes, void* stream) {
     if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !dw) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
+    if (m_out > 0 && (!x || !dy || !nbr)) return SEG3D_EINVAL;
+    // split-bf16: partial blocks per row chunk in the workspace, summed in a fixed order (writes all of dw)
+    if (m_out > 0 && (flags & 4)) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, workspace, workspace_bytes, st);
     if (hipMemsetAsync(dw, 0, (size_t)27 * cin * cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
     if (m_out == 0) return SEG3D_OK;
-    if (!x || !dy || !nbr) return SEG3D_EINVAL;
-    if (flags & 4) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, st);
     const int ja = pick_j(cin), jb = pick_j(cout);
     switch (ja) {
         case 4: return launch_wgrad_b<4>(jb, x, dy, nbr, m_out, cin, cout, dw, st);

@@ -213,6 +213,13 @@ __global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restric
 
 }  // namespace
 
+// part[chunks][n] -> dw[0, nw) and db[0, n - nw) (db nullable); also used by the sparse wgrad (wgrad_split.hip)
+int wgrad_chunk_reduce(const float* part, int chunks, int64_t n, int64_t nw, float* dw, float* db, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(n, 32)), dim3(256), 0, st, part, chunks, n, nw, dw, db);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
 extern "C" size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int32_t cout) {
     if (m < 0 || cin <= 0 || cout <= 0) return 0;
     const Plan p = plan(m, cin, cout);
@@ -235,9 +242,6 @@ extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, in
         SEG3D_CHECK_LAUNCH();
     }
     // without db the trailing [cout] columns of each partial are never written; their sums are discarded
-    const int64_t nw = (int64_t)cin * cout, stride = nw + cout;
-    hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(stride, 32)), dim3(256), 0, st, part, p.chunks, stride,
-                       nw, dw, db);
-    SEG3D_CHECK_LAUNCH();
-    return SEG3D_OK;
+    const int64_t nw = (int64_t)cin * cout;
+    return wgrad_chunk_reduce(part, p.chunks, nw + cout, nw, dw, db, st);
 }

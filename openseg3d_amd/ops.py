@@ -236,8 +236,10 @@ class _SparseConvFn(torch.autograd.Function):
             dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, dtype=torch.float32)
+            ws_bytes = _lib.query("seg3d_spconv_wgrad_workspace_bytes", dy.shape[0], cin, cout)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
             _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
-                      _precision_flag(), _ptr(dw), None, 0, _stream())
+                      _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None, None, None
