@@ -9,10 +9,13 @@
 // Tile: 4 waves x (RB x 16) output rows x (NBT x 16) columns.  Work is a stream of chunks
 // (active kernel offset k, 32 input channels).  Per chunk the workgroup copies the pre-split W_k fragments
 // (NBT x 2 KiB, contiguous in the packed stream) straight into a double-buffered LDS slot with
-// global_load_lds_dwordx4 (no VGPR staging), every wave gathers its neighbour rows (32 B per lane),
-// splits them in registers and issues RB x NBT x 3 v_mfma_f32_16x16x32_bf16.  The copy and the gather of
-// chunk c+1 are in flight while chunk c computes; one barrier per chunk.  Offsets with no active
+// register-staged 16-B loads, every wave gathers its neighbour rows (32 B per lane), splits them in
+// registers and issues RB x NBT x 3 v_mfma_f32_16x16x32_bf16.  The W loads and the gather of chunk c+1 are
+// in flight while chunk c computes (their waits sit behind the MFMAs); one barrier per chunk; the table
+// entries of the next offset are loaded one offset ahead.  Offsets with no active
 // neighbour in the whole tile are never visited; a wave whose own rows have none skips gather and MFMAs.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -74,9 +77,6 @@ __global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict
     wp[t] = h ? (__bf16)(v - (float)hi) : hi;
 }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
-
 template <int NBT, int RB, bool DENSE>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
@@ -134,26 +134,39 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             grow_ok[rb] = r < m_out;
             grow[rb] = grow_ok[rb] ? r : last_row;
         }
-        auto load_idx = [&](int k, int32_t* idx) {
+        // neighbour rows of offset k for this lane's RB rows (raw loads; the caller decides when to look at them)
+        auto fetch_idx = [&](int k, int32_t* idx) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) idx[rb] = DENSE ? (int32_t)grow[rb] : nbr[(int64_t)k * m_out + grow[rb]];
+        };
+        auto any_active = [&](int32_t* idx) {
             bool any = false;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int32_t v = DENSE ? (int32_t)grow[rb] : nbr[(int64_t)k * m_out + grow[rb]];
-                idx[rb] = grow_ok[rb] ? v : -1;
+                idx[rb] = grow_ok[rb] ? idx[rb] : -1;
                 any |= idx[rb] >= 0;
             }
             return __ballot(any) != 0ull;
         };
-        // W chunk -> LDS slot, asynchronously: piece j (1 KiB) is issued by wave j % 4
-        auto stage_w = [&](int k, int cb, int buf) {
+        // W chunk -> registers now, -> LDS slot after the MFMAs of the current chunk: piece j (1 KiB) belongs to wave
+        // j % 4.  (An LDS-DMA copy would save the registers, but the compiler then drains vmcnt before the first
+        // ds_read of the current chunk -- it cannot tell the slots apart -- and nothing overlaps.)
+        constexpr int kMine = (kPieces + kW - 1) / kW;
+        u32x4 wreg[kMine];  // ext-vector type: HIP's uint4 struct is not promoted out of scratch here
+        auto stage_w = [&](int k, int cb) {
             const uint4* src = wp + (((int64_t)k * cb_n + cb) * nb_n + nb0) * 128;
 #pragma unroll
-            for (int j = 0; j < (kPieces + kW - 1) / kW; ++j) {
+            for (int j = 0; j < kMine; ++j) {
                 const int piece = j * kW + wave;
-                if (kPieces % kW == 0 || piece < kPieces) {
-                    __builtin_amdgcn_global_load_lds((gbl_void*)(src + piece * 64 + lane),
-                                                     (lds_void*)(wlds + buf * kSlot + piece * 64), 16, 0, 0);
-                }
+                wreg[j] = *reinterpret_cast<const u32x4*>(src + (kPieces % kW == 0 || piece < kPieces ? piece : 0) * 64 + lane);
+            }
+        };
+        auto commit_w = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < kMine; ++j) {
+                const int piece = j * kW + wave;
+                if (kPieces % kW == 0 || piece < kPieces)
+                    *reinterpret_cast<u32x4*>(wlds + buf * kSlot + piece * 64 + lane) = wreg[j];
             }
         };
         f32x4 areg[RB][2];
@@ -182,14 +195,17 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         int k_cur = __builtin_ctz(todo);
         todo &= todo - 1;
         int cb_cur = 0;
-        int32_t idx_cur[RB];
-        bool on_cur = load_idx(k_cur, idx_cur);
+        int32_t idx_cur[RB], idx_pre[RB];  // idx_pre: the table entries of the offset after k_cur, loaded one offset ahead
+        fetch_idx(k_cur, idx_cur);
+        bool on_cur = any_active(idx_cur);
+        if (todo != 0u) fetch_idx(__builtin_ctz(todo), idx_pre);
 
         // prologue: chunk 0
-        stage_w(k_cur, 0, 0);
+        stage_w(k_cur, 0);
         issue_a(idx_cur, 0, on_cur);
         land_a();
-        __syncthreads();  // hipcc drains vmcnt before the barrier: the LDS-DMA pieces have landed
+        commit_w(0);
+        __syncthreads();
 
         int buf = 0;
         for (;;) {
@@ -205,11 +221,14 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                 } else {
                     k_nxt = __builtin_ctz(todo);
                     todo &= todo - 1;
-                    on_nxt = load_idx(k_nxt, idx_nxt);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) idx_nxt[rb] = idx_pre[rb];
+                    on_nxt = any_active(idx_nxt);
+                    if (todo != 0u) fetch_idx(__builtin_ctz(todo), idx_pre);
                 }
             }
             if (have_next) {
-                stage_w(k_nxt, cb_nxt, buf ^ 1);
+                stage_w(k_nxt, cb_nxt);
                 issue_a(idx_nxt, cb_nxt, on_nxt);
             }
             if (on_cur) {
@@ -228,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             }
             if (!have_next) break;
             land_a();
+            commit_w(buf ^ 1);
             __syncthreads();
             buf ^= 1;
             k_cur = k_nxt;
@@ -285,13 +305,29 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
                      int cout, float* y, hipStream_t st) {
+    // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
+    // (19k, 7k) and wide channels and run better on twice as many 96-column workgroups (measured per layer,
+    // profiles/README.md); narrower tiles re-gather the rows too often.
     const int nb = cout / 16;
-    if (nb % 12 == 0) return launch_split<12, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-    if (nb % 6 == 0) return launch_split<6, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-    if (nb % 4 == 0) return launch_split<4, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-    if (nb % 3 == 0) return launch_split<3, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-    if (nb % 2 == 0) return launch_split<2, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-    return launch_split<1, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    const int64_t row_tiles = ceil_div64(m_out, 4 * 2 * 16);
+    int pick = 1;
+    if (nb % 12 == 0) pick = row_tiles >= 400 ? 12 : 6;
+    else if (nb % 6 == 0) pick = 6;
+    else if (nb % 4 == 0) pick = 4;
+    else if (nb % 3 == 0) pick = 3;
+    else if (nb % 2 == 0) pick = 2;
+    if (const char* e = getenv("SEG3D_CONV_NBT")) {
+        const int w = atoi(e);
+        if (w > 0 && nb % w == 0) pick = w;
+    }
+    switch (pick) {
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+    }
 }
 
 // ------------------------------------------------------------------ dense Linear layers through the same kernel
