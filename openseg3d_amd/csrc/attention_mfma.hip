@@ -10,14 +10,16 @@
 //        Qp, Kp : [padded position][head][DHS]   (row-major; an MFMA A/B fragment = one 16-B load)
 //        Vt     : [head][d][padded position]     (transposed, positions permuted inside a tile so that the
 //                                                 score accumulator of the QK^T MFMAs is the B operand of PV)
-//  2. attn_core_fwd: one wave per (window, 16-query group, head).  Per 32-key tile: S^T = K.Q^T as
-//     2 x ksteps x 3 v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi), online softmax in registers (the 8
+//  2. attn_core_fwd: one wave per (window, 32-query tile, head).  Per 32-key tile and 16-query group: S^T = K.Q^T
+//     as 2 x ksteps x 3 v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi), online softmax in registers (the 8
 //     scores a lane holds all belong to its own query column; row max/sum = 2 shuffles), P split to bf16
 //     hi/lo in place, O^T += V^T.P as d-blocks x 3 MFMAs.  Results go straight to flat voxel order.
 // Work items (tiles, query groups) come from seg3d_window_partition, so no thread ever sees an empty window.
 //
 // Algorithmic FLOPs: 4*C*sum_w n_w^2 per layer; executed MFMA FLOPs are 3x that (split) plus
 // tile padding.  Error: ~2^-16 relative per product (same budget as the sparse convs).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -131,84 +133,119 @@ __global__ __launch_bounds__(256) void attn_prepare_fwd(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ core
+// One wave per (32-query tile of a window, head), looping over the window's 32-key tiles: every K / V fragment it
+// loads serves two 16-query groups (the K/V re-reads of the large windows are what bounds this kernel:
+// sum_w n_w^2 / 32 * heads * 2 * (DHS + DH) * 2 bytes per layer); the second group is skipped (wave-uniform) when
+// the tile holds <= 16 queries.
+// Addressing: what depends on (item, head, tile) is wave-uniform and lives in scalar base pointers; the lane's share
+// is a constant 32-bit byte offset.  No register prefetch -- measured: the extra stage registers cost more
+// occupancy than the prefetch hides.  Only the last key tile masks keys >= n.
+// Channel slices past DHS are zeroed in Q (so K needs no mask); V rows past DH only feed output rows that are never stored.
 template <int DH>
 __global__ __launch_bounds__(256) void attn_core_fwd(const __bf16* __restrict__ qp, const __bf16* __restrict__ kp,
                                                      const __bf16* __restrict__ vt, const int32_t* __restrict__ tok,
                                                      const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-                                                     const int32_t* __restrict__ win_tile0, const int2* __restrict__ qg_item,
+                                                     const int32_t* __restrict__ win_tile0, const int2* __restrict__ tile_item,
                                                      int n_items, int heads, int64_t mpad, float* __restrict__ out,
                                                      float* __restrict__ lse) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int it = blockIdx.x * 4 + wave;
-    if (it >= n_items) return;  // wave-uniform
-    const int h = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (it >= n_items) return;
     const int g = lane >> 4, c16 = lane & 15;
-    const int2 item = qg_item[it];
+    const int2 item = tile_item[it];
     const int n = win_count[item.x], start = win_start[item.x];
     const int64_t pos0 = (int64_t)win_tile0[item.x] * 32;
-    const int n_tiles = (n + 31) >> 5;
+    const int n_kt = (n + 31) >> 5;
+    const int q0 = item.y * 32;
+    const bool two = n - q0 > 16;  // the tile's second 16-query group exists (wave-uniform)
     const int64_t qk_half = mpad * heads * DHS;
     const int64_t vt_half = (int64_t)heads * DH * mpad;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    // Q fragments of this wave's 16 queries: B operand, lane (query c16, channels 32s + 8g .. +7)
-    const int qi = item.y * 16 + c16;
-    bf16x8 q_hi[KS], q_lo[KS];
+    // lane byte offsets; channel slices / d rows that do not exist read slice 0 / row 0
+    uint32_t koff[2][KS], qoff[2][KS], voff[NB];
+    bool slice_ok[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        u32x4 a = zero4, b = zero4;
-        if (32 * s + 8 * g < DHS) {
-            const int64_t o = ((pos0 + qi) * heads + h) * DHS + 32 * s + 8 * g;
-            a = *reinterpret_cast<const u32x4*>(qp + o);
-            b = *reinterpret_cast<const u32x4*>(qp + qk_half + o);
-        }
-        q_hi[s] = __builtin_bit_cast(bf16x8, a);
-        q_lo[s] = __builtin_bit_cast(bf16x8, b);
-    }
-
-    f32x4 o_acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) o_acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    for (int t = 0; t < n_tiles; ++t) {
-        // ---- S^T tile: two 16-key sub-tiles
-        f32x4 s_acc[2];
+        slice_ok[s] = 32 * s + 8 * g < DHS;
+        const int sl = slice_ok[s] ? 32 * s + 8 * g : 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            s_acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int64_t krow = pos0 + t * 32 + u * 16 + c16;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                u32x4 a = zero4, b = zero4;
-                if (32 * s + 8 * g < DHS) {
-                    const int64_t o = (krow * heads + h) * DHS + 32 * s + 8 * g;
-                    a = *reinterpret_cast<const u32x4*>(kp + o);
-                    b = *reinterpret_cast<const u32x4*>(kp + qk_half + o);
-                }
-                const bf16x8 k_hi = __builtin_bit_cast(bf16x8, a), k_lo = __builtin_bit_cast(bf16x8, b);
-                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_lo, q_hi[s], s_acc[u], 0, 0, 0);
-                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_lo[s], s_acc[u], 0, 0, 0);
-                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_hi[s], s_acc[u], 0, 0, 0);
-            }
+            koff[u][s] = (uint32_t)(((u * 16 + c16) * heads * DHS + sl) * 2);
+            qoff[u][s] = (uint32_t)(((q0 + u * 16 + c16) * heads * DHS + sl) * 2);
         }
-        // ---- online softmax over this lane's query column (keys: 4g + r in each sub-tile)
-        float sc[8];
-        float tmax = -INFINITY;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) voff[b] = (uint32_t)(((int64_t)(16 * b + c16 < DH ? 16 * b + c16 : 0) * mpad + 8 * g) * 2);
+    const int64_t kstep = (int64_t)32 * heads * DHS * 2;
+    // token rows of this lane's two queries
+    int32_t token[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) token[j] = q0 + 16 * j + c16 < n ? tok[start + q0 + 16 * j + c16] : -1;
+
+    u32x4 kf[2][2][KS][2], vf[2][NB][2];  // [stage][..][hi, lo]
+    auto fetch = [&](int h, int t, auto stage) {
+        constexpr int S = decltype(stage)::value;
+        const char* kb = reinterpret_cast<const char*>(kp + (pos0 * heads + h) * DHS) + t * kstep;
+        const char* vb = reinterpret_cast<const char*>(vt + (int64_t)h * DH * mpad + pos0) + t * 64;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 32 + u * 16 + g * 4 + r;
-                const float x = key < n ? s_acc[u][r] : -INFINITY;
-                sc[u * 4 + r] = x;
-                tmax = fmaxf(tmax, x);
+            for (int s = 0; s < KS; ++s) {
+                kf[S][u][s][0] = *reinterpret_cast<const u32x4*>(kb + koff[u][s]);
+                kf[S][u][s][1] = *reinterpret_cast<const u32x4*>(kb + qk_half * 2 + koff[u][s]);
             }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            vf[S][b][0] = *reinterpret_cast<const u32x4*>(vb + voff[b]);
+            vf[S][b][1] = *reinterpret_cast<const u32x4*>(vb + vt_half * 2 + voff[b]);
+        }
+    };
+    // Q fragments of the two query groups: B operand, lane (query c16, channels 32s + 8g .. +7)
+    u32x4 qf[2][KS][2];
+    auto load_q = [&](int h) {
+        const char* qb = reinterpret_cast<const char*>(qp + (pos0 * heads + h) * DHS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(qb + qoff[j][s]);
+                const u32x4 b = *reinterpret_cast<const u32x4*>(qb + qk_half * 2 + qoff[j][s]);
+                qf[j][s][0] = slice_ok[s] ? a : zero4;
+                qf[j][s][1] = slice_ok[s] ? b : zero4;
+            }
+    };
+
+    f32x4 o_acc[2][NB];
+    float m_run[2], l_run[2];
+    auto reset = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            m_run[j] = -INFINITY;
+            l_run[j] = 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) o_acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // one key tile for query group j: scores, online softmax, O^T += V^T . P
+    auto group_tile = [&](int j, int t, auto stage, bool last, f32x4 (&s_acc)[2]) {
+        constexpr int S = decltype(stage)::value;
+        float sc[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[u * 4 + r] = s_acc[u][r];
+        if (last) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, SEG3D_WAVE));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, SEG3D_WAVE));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run[j], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -217,9 +254,8 @@ __global__ __launch_bounds__(256) void attn_core_fwd(const __bf16* __restrict__ 
         }
         psum += __shfl_xor(psum, 16, SEG3D_WAVE);
         psum += __shfl_xor(psum, 32, SEG3D_WAVE);
-        l_run = fmaf(l_run, alpha, psum);
-        m_run = m_new;
-        // ---- P fragment (B operand of PV): hi/lo split in place
+        l_run[j] = fmaf(l_run[j], alpha, psum);
+        m_run[j] = m_new;
         u32x4 ph, pl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -230,38 +266,73 @@ __global__ __launch_bounds__(256) void attn_core_fwd(const __bf16* __restrict__ 
             pl[i] = pack_bf16(sc[2 * i] - h0, sc[2 * i + 1] - h1);
         }
         const bf16x8 p_hi = __builtin_bit_cast(bf16x8, ph), p_lo = __builtin_bit_cast(bf16x8, pl);
-        // ---- O^T += V^T . P
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            u32x4 a = zero4, c = zero4;
-            const int d = 16 * b + c16;
-            if (d < DH) {
-                const int64_t o = ((int64_t)h * DH + d) * mpad + pos0 + t * 32 + 8 * g;
-                a = *reinterpret_cast<const u32x4*>(vt + o);
-                c = *reinterpret_cast<const u32x4*>(vt + vt_half + o);
-            }
-            const bf16x8 v_hi = __builtin_bit_cast(bf16x8, a), v_lo = __builtin_bit_cast(bf16x8, c);
-            f32x4 acc = o_acc[b] * alpha;
+            const bf16x8 v_hi = __builtin_bit_cast(bf16x8, vf[S][b][0]), v_lo = __builtin_bit_cast(bf16x8, vf[S][b][1]);
+            f32x4 acc = o_acc[j][b] * alpha;
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_lo, p_hi, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_lo, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_hi, acc, 0, 0, 0);
-            o_acc[b] = acc;
+            o_acc[j][b] = acc;
         }
-    }
-
-    // ---- epilogue: O^T[d = 16b + 4g + r][query c16] / l  ->  out[token][h*DH + d]
-    if (qi < n) {
-        const int32_t token = tok[start + qi];
-        const float inv = 1.0f / l_run;
-        float* op = out + (int64_t)token * (heads * DH) + h * DH;
+    };
+    auto scores = [&](int j, auto stage, f32x4 (&s_acc)[2]) {
+        constexpr int S = decltype(stage)::value;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int u = 0; u < 2; ++u) {
+            s_acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * b + 4 * g + r;
-                if (d < DH) op[d] = o_acc[b][r] * inv;
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 k_hi = __builtin_bit_cast(bf16x8, kf[S][u][s][0]);
+                const bf16x8 k_lo = __builtin_bit_cast(bf16x8, kf[S][u][s][1]);
+                const bf16x8 q_hi = __builtin_bit_cast(bf16x8, qf[j][s][0]);
+                const bf16x8 q_lo = __builtin_bit_cast(bf16x8, qf[j][s][1]);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_lo, q_hi, s_acc[u], 0, 0, 0);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_lo, s_acc[u], 0, 0, 0);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_hi, s_acc[u], 0, 0, 0);
             }
-        if (lse && g == 0) lse[(int64_t)token * heads + h] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
+        }
+    };
+    // epilogue of a head: O^T[d = 16b + 4g + r][query c16] / l  ->  out[token][h*DH + d]
+    auto finish = [&](int h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (token[j] < 0) continue;
+            const float inv = 1.0f / l_run[j];
+            float* op = out + (int64_t)token[j] * (heads * DH) + h * DH;
+            // a lane's 4 accumulator rows are 4 consecutive channels of its query: one 16-B store (8-B for DH = 6)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int d = 16 * b + 4 * g;
+                const f32x4 o = o_acc[j][b] * inv;
+                if (DH % 4 == 0) {
+                    if (d < DH) *reinterpret_cast<f32x4*>(op + d) = o;
+                } else {
+                    if (d + 1 < DH) *reinterpret_cast<f32x2*>(op + d) = (f32x2){o[0], o[1]};
+                    if (d + 3 < DH) *reinterpret_cast<f32x2*>(op + d + 2) = (f32x2){o[2], o[3]};
+                }
+            }
+            if (lse && g == 0) lse[(int64_t)token[j] * heads + h] = (m_run[j] + __builtin_amdgcn_logf(l_run[j])) * kLn2;
+        }
+    };
+    auto step = [&](int h, int t, auto stage) {
+        const bool last = t + 1 == n_kt;
+        f32x4 s0[2], s1[2];
+        scores(0, stage, s0);
+        if (two) scores(1, stage, s1);
+        group_tile(0, t, stage, last, s0);
+        if (two) group_tile(1, t, stage, last, s1);
+        if (last) finish(h);
+    };
+
+    using St0 = std::integral_constant<int, 0>;
+    const int total = n_kt;
+    const int h = blockIdx.y;
+    reset();
+    load_q(h);
+    for (int t = 0; t < total; ++t) {  // no register prefetch: the other waves of the SIMD cover the latency
+        fetch(h, t, St0{});
+        step(h, t, St0{});
     }
 }
 
@@ -288,8 +359,10 @@ int run_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     hipLaunchKernelGGL(attn_prepare_fwd<DH>, dim3((unsigned)n_tiles), dim3(256), smem, st, q, k, v, ldq, ldk, ldv, tok,
                        win_start, win_count, win_tile0, tile_item, heads, mpad, tau, tau_min, qp, kp, vt);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_core_fwd<DH>, dim3((unsigned)((n_qg + 3) / 4), (unsigned)heads), dim3(256), 0, st, qp, kp, vt,
-                       tok, win_start, win_count, win_tile0, qg_item, n_qg, heads, mpad, out, lse);
+    (void)qg_item;
+    (void)n_qg;
+    hipLaunchKernelGGL(attn_core_fwd<DH>, dim3((unsigned)((n_tiles + 3) / 4), (unsigned)heads), dim3(256), 0, st, qp, kp, vt, tok, win_start,
+                       win_count, win_tile0, tile_item, n_tiles, heads, mpad, out, lse);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

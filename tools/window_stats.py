@@ -1,0 +1,30 @@
+"""Print the window-size distribution of the bench scene per encoder stage (GPU box only)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from openseg3d_amd import batch as B, config, ops, scene, segformer
+
+dev = torch.device("cuda:0")
+cfg = config.default_cfg()
+ds = config.DatasetSpec(cfg)
+model = segformer.build_segmentor(cfg, ds).to(dev).eval()
+orig = ops.window_partition
+seen = []
+
+
+def spy(*a, **k):
+    w = orig(*a, **k)
+    n = w.win_count.cpu().numpy().astype("int64")
+    n = n[n > 0]
+    seen.append((int(w.tok.shape[0]), int(n.shape[0]), int(n.max()), float(n.mean()), float((n * n).sum()), int((n > 512).sum()),
+                 int((n > 1024).sum())))
+    return w
+
+
+ops.window_partition = spy
+b = B.make_batch([scene.make_scene(0)], ds.voxel_size, ds.point_cloud_range)
+with torch.no_grad():
+    model(b)
+for s in seen:
+    print("tokens %6d windows %5d max %5d mean %6.1f sum_n2 %.3g  >512: %d  >1024: %d" % s)
