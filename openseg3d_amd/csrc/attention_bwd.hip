@@ -6,9 +6,9 @@
 //  1. attn_prepare_bwd (one workgroup per 32-token tile): gathers q, k, v, dO rows, normalises q/k, splits to
 //     bf16 hi/lo and writes row-major copies (Qp, Kp, Vp, Gp) and tile-permuted transposed copies (Qt, Kt,
 //     Gt), plus per (token, head) the log2-domain LSE and delta = <dO, O>.
-//  2. attn_bwd_q: one wave per (window, 16-query group, head), loop over 32-key tiles:
+//  2. attn_bwd_q: one wave per (window, 32-query tile, head), loop over 32-key tiles, per 16-query group:
 //        S^T = K.Q^T, dP^T = V.dO^T, P = exp2(S - L), dS = P (dP - delta), dQ^T += K^T.dS^T, dtau += <dS, S>
-//  3. attn_bwd_kv: one wave per (window, 16-key group, head), loop over 32-query tiles:
+//  3. attn_bwd_kv: one wave per (window, 32-key tile, head), loop over 32-query tiles, per 16-key group:
 //        S = Q.K^T, dP = dO.V^T, P, dS as above, dV^T += dO^T.P, dK^T += Q^T.dS
 //  The accumulator layout of the first two products is exactly the B-operand layout of the last ones (tokens
 //  permuted inside a tile, attn_common.hpp), so nothing moves between lanes and no LDS is used.  Each wave
@@ -25,7 +25,7 @@ template <int DH>
 struct BwdWs {
     __bf16 *qp, *kp, *vp, *gp;  // row-major  [mpad][heads][DHS], hi block then lo block
     __bf16 *qt, *kt, *gt;       // transposed [heads][DH][mpad],  hi block then lo block
-    float *lp, *dp;             // [mpad][heads]: log2-domain LSE, delta
+    float *lp, *dp;             // [heads][mpad]: log2-domain LSE, delta
     float* tau_part;            // [256] partial tau gradients (one address would serialise ~1e5 atomics)
     static size_t row_bytes(int64_t mpad, int heads) {
         return align_up((size_t)mpad * heads * Geo<DH>::DHS * 2 * sizeof(__bf16), 256);
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void attn_prepare_bwd(const float* __restrict_
 #pragma unroll
                         for (int d = 0; d < DH; ++d) s = fmaf(buf[row * cp + h * DH + d], op[d], s);
                     }
-                    ws.dp[(pos0 + row) * heads + h] = s;
-                    ws.lp[(pos0 + row) * heads + h] = t >= 0 ? lse[(int64_t)t * heads + h] * kLog2e : 0.f;
+                    ws.dp[(int64_t)h * mpad + pos0 + row] = s;
+                    ws.lp[(int64_t)h * mpad + pos0 + row] = t >= 0 ? lse[(int64_t)t * heads + h] * kLog2e : 0.f;
                 }
             }
         }
@@ -178,102 +178,162 @@ __device__ __forceinline__ void through_normalise(const float* __restrict__ xrow
         for (int r = 0; r < 4; ++r) grad[b][r] = clamped ? grad[b][r] * rinv : (grad[b][r] - xr[b][r] * proj) * rinv;
 }
 
+// ------------------------------------------------------------------ shared addressing of the two passes
+// One wave per (32-token tile of a window, head): the tile's tokens are the stationary operand (two 16-column
+// groups; the second is skipped, wave-uniform, when the tile holds <= 16 tokens), the window's 32-token tiles
+// stream past it and every streamed fragment serves both groups.  What depends on (item, head, streamed tile) is
+// wave-uniform and lives in scalar base pointers; the lane's share is a constant 32-bit byte offset.  Channel
+// slices past DHS are zeroed in the stationary fragments (the streamed ones need no mask); transposed rows
+// past DH only feed output rows that are never stored.  Only the last streamed tile masks tokens >= n.
+template <int DH>
+struct Lanes {
+    static constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
+    uint32_t row[2][KS];  // row-major fragment of streamed token 16u + c16, slice s
+    uint32_t tr[NB];      // transposed fragment: row d = 16b + c16, token slots 8g .. 8g+7
+    bool slice_ok[KS];
+    __device__ Lanes(int g, int c16, int heads, int64_t mpad) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            slice_ok[s] = 32 * s + 8 * g < DHS;
+            const int sl = slice_ok[s] ? 32 * s + 8 * g : 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) row[u][s] = (uint32_t)(((u * 16 + c16) * heads * DHS + sl) * 2);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tr[b] = (uint32_t)(((int64_t)(16 * b + c16 < DH ? 16 * b + c16 : 0) * mpad + 8 * g) * 2);
+    }
+};
+
+__device__ __forceinline__ void ld2(const char* base, int64_t half_bytes, uint32_t off, bf16x8* hi, bf16x8* lo) {
+    *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + off));
+    *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + half_bytes + off));
+}
+
 // ------------------------------------------------------------------ pass A: dq, dtau
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __restrict__ q, int ldq,
                                                   const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                   const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
-                                                  const int2* __restrict__ qg_item, int n_items, int heads, int64_t mpad,
+                                                  const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
                                                   const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
                                                   int lddq) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int it = blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63;
+    const int it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (it >= n_items) return;
     const int h = blockIdx.y, g = lane >> 4, c16 = lane & 15;
-    const int2 item = qg_item[it];
+    const int2 item = tile_item[it];
     const int n = win_count[item.x], start = win_start[item.x];
     const int64_t pos0 = (int64_t)win_tile0[item.x] * 32;
-    const int n_tiles = (n + 31) >> 5;
-    const int64_t row_half = mpad * heads * DHS, tr_half = (int64_t)heads * DH * mpad;
-    const int qi = item.y * 16 + c16;
-    const int64_t qpos = pos0 + qi;
+    const int n_kt = (n + 31) >> 5;
+    const int q0 = item.y * 32;
+    const bool two = n - q0 > 16;
+    const int64_t row_half = mpad * heads * DHS * 2, tr_half = (int64_t)heads * DH * mpad * 2;  // bytes
+    const Lanes<DH> L(g, c16, heads, mpad);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const bf16x8 zf = __builtin_bit_cast(bf16x8, zero4);
 
-    bf16x8 q_hi[KS], q_lo[KS], g_hi[KS], g_lo[KS];
+    // stationary: Q and dO fragments of the two query groups (B operands), LSE and delta of the lane's queries
+    bf16x8 q_hi[2][KS], q_lo[2][KS], g_hi[2][KS], g_lo[2][KS];
+    float lq[2], dl[2];
+    {
+        const char* qb = reinterpret_cast<const char*>(ws.qp + ((pos0 + q0) * heads + h) * DHS);
+        const char* gb = reinterpret_cast<const char*>(ws.gp + ((pos0 + q0) * heads + h) * DHS);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const bool ok = 32 * s + 8 * g < DHS;
-        const int64_t o = (qpos * heads + h) * DHS + 32 * s + 8 * g;
-        load_frag(ws.qp, o, row_half, ok, &q_hi[s], &q_lo[s]);
-        load_frag(ws.gp, o, row_half, ok, &g_hi[s], &g_lo[s]);
-    }
-    const float lq = ws.lp[qpos * heads + h], dq_delta = ws.dp[qpos * heads + h];
-
-    f32x4 acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float tau_acc = 0.f;
-
-    for (int t = 0; t < n_tiles; ++t) {
-        float dsv[8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
-            const int64_t krow = pos0 + t * 32 + u * 16 + c16;
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bool ok = 32 * s + 8 * g < DHS;
-                const int64_t o = (krow * heads + h) * DHS + 32 * s + 8 * g;
-                bf16x8 a_hi, a_lo;
-                load_frag(ws.kp, o, row_half, ok, &a_hi, &a_lo);
-                s_acc = mfma3(a_hi, a_lo, q_hi[s], q_lo[s], s_acc);   // S^T[key][query]
-                load_frag(ws.vp, o, row_half, ok, &a_hi, &a_lo);
-                p_acc = mfma3(a_hi, a_lo, g_hi[s], g_lo[s], p_acc);   // dP^T[key][query]
+                ld2(qb, row_half, L.row[j][s], &q_hi[j][s], &q_lo[j][s]);
+                ld2(gb, row_half, L.row[j][s], &g_hi[j][s], &g_lo[j][s]);
+                if (!L.slice_ok[s]) q_hi[j][s] = q_lo[j][s] = g_hi[j][s] = g_lo[j][s] = zf;
+            }
+            lq[j] = ws.lp[(int64_t)h * mpad + pos0 + q0 + 16 * j + c16];
+            dl[j] = ws.dp[(int64_t)h * mpad + pos0 + q0 + 16 * j + c16];
+        }
+    }
+    f32x4 acc[2][NB];
+    float tau_acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t kstep = (int64_t)32 * heads * DHS * 2;
+    const char* kb = reinterpret_cast<const char*>(ws.kp + (pos0 * heads + h) * DHS);
+    const char* vb = reinterpret_cast<const char*>(ws.vp + (pos0 * heads + h) * DHS);
+    const char* ktb = reinterpret_cast<const char*>(ws.kt + (int64_t)h * DH * mpad + pos0);
+    for (int t = 0; t < n_kt; ++t) {
+        const bool last = t + 1 == n_kt;
+        bf16x8 k_hi[2][KS], k_lo[2][KS], v_hi[2][KS], v_lo[2][KS], kt_hi[NB], kt_lo[NB];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                ld2(kb + t * kstep, row_half, L.row[u][s], &k_hi[u][s], &k_lo[u][s]);
+                ld2(vb + t * kstep, row_half, L.row[u][s], &v_hi[u][s], &v_lo[u][s]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 32 + u * 16 + g * 4 + r;
-                const float p = key < n ? __builtin_amdgcn_exp2f(s_acc[r] - lq) : 0.f;
-                const float ds = p * (p_acc[r] - dq_delta);
-                dsv[u * 4 + r] = ds;
-                tau_acc = fmaf(ds, s_acc[r], tau_acc);
-            }
-        }
-        bf16x8 ds_hi, ds_lo;
-        split_frag(dsv, &ds_hi, &ds_lo);
+        for (int b = 0; b < NB; ++b) ld2(ktb + t * 64, tr_half, L.tr[b], &kt_hi[b], &kt_lo[b]);
+        auto group = [&](int j) {
+            float dsv[8];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int d = 16 * b + c16;
-            bf16x8 a_hi, a_lo;
-            load_frag(ws.kt, ((int64_t)h * DH + d) * mpad + pos0 + t * 32 + 8 * g, tr_half, d < DH, &a_hi, &a_lo);
-            acc[b] = mfma3(a_hi, a_lo, ds_hi, ds_lo, acc[b]);         // dQhat^T[d][query] * tau_c
-        }
+            for (int u = 0; u < 2; ++u) {
+                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    s_acc = mfma3(k_hi[u][s], k_lo[u][s], q_hi[j][s], q_lo[j][s], s_acc);  // S^T[key][query]
+                    p_acc = mfma3(v_hi[u][s], v_lo[u][s], g_hi[j][s], g_lo[j][s], p_acc);  // dP^T[key][query]
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[j]);
+                    if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;
+                    const float ds = p * (p_acc[r] - dl[j]);
+                    dsv[u * 4 + r] = ds;
+                    tau_acc[j] = fmaf(ds, s_acc[r], tau_acc[j]);
+                }
+            }
+            bf16x8 ds_hi, ds_lo;
+            split_frag(dsv, &ds_hi, &ds_lo);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[j][b] = mfma3(kt_hi[b], kt_lo[b], ds_hi, ds_lo, acc[j][b]);  // dQhat^T[d][query] * tau_c
+        };
+        group(0);
+        if (two) group(1);
     }
 
     const float tau_c = fmaxf(tau[0], tau_min);
-    if (qi < n) {
-        const float inv_tau = 1.0f / tau_c;
+    const float inv_tau = 1.0f / tau_c;
+    float tau_sum = 0.f;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = acc[b] * inv_tau;
-    } else {
-        tau_acc = 0.f;
-    }
-    // every lane of a query column takes part in the shuffles; invalid columns read row 0 and store nothing
-    const int32_t token = tok[start + (qi < n ? qi : 0)];
-    through_normalise<DH>(q + (int64_t)token * ldq + h * DH, g, acc);
-    if (qi < n) {
-        float* o = dq + (int64_t)token * lddq + h * DH;
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const int qi = q0 + 16 * j + c16;
+        const bool valid = qi < n;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b) acc[j][b] = acc[j][b] * inv_tau;
+        if (valid) tau_sum += tau_acc[j];
+        // every lane of a query column takes part in the shuffles; invalid columns read row 0 and store nothing
+        const int32_t token = tok[start + (valid ? qi : 0)];
+        through_normalise<DH>(q + (int64_t)token * ldq + h * DH, g, acc[j]);
+        if (valid) {
+            float* o = dq + (int64_t)token * lddq + h * DH;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * b + 4 * g + r;
-                if (d < DH) o[d] = acc[b][r];
+            for (int b = 0; b < NB; ++b) {
+                const int d = 16 * b + 4 * g;
+                if (DH % 4 == 0) {
+                    if (d < DH) *reinterpret_cast<f32x4*>(o + d) = acc[j][b];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (d + r < DH) o[d + r] = acc[j][b][r];
+                }
             }
+        }
     }
     // d/dtau: s_nat = s2 * ln2 = c / tau  ->  dL/dtau = -sum(ds * s_nat) / tau   (zero while tau is clamped)
-    for (int off = 32; off > 0; off >>= 1) tau_acc += __shfl_xor(tau_acc, off, SEG3D_WAVE);
-    if (lane == 0 && tau[0] > tau_min && tau_acc != 0.f) atomicAdd(&ws.tau_part[it & 255], -tau_acc * kLn2 / tau_c);
+    for (int off = 32; off > 0; off >>= 1) tau_sum += __shfl_xor(tau_sum, off, SEG3D_WAVE);
+    if (lane == 0 && tau[0] > tau_min && tau_sum != 0.f) atomicAdd(&ws.tau_part[it & 255], -tau_sum * kLn2 / tau_c);
 }
 
 __global__ __launch_bounds__(256) void tau_reduce(const float* __restrict__ part, float* __restrict__ dtau) {
@@ -290,95 +350,134 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_kv(BwdWs<DH> ws, const float* __restrict__ k, int ldk,
                                                    const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                    const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
-                                                   const int2* __restrict__ kg_item, int n_items, int heads, int64_t mpad,
+                                                   const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
                                                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int it = blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63;
+    const int it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (it >= n_items) return;
     const int h = blockIdx.y, g = lane >> 4, c16 = lane & 15;
-    const int2 item = kg_item[it];
+    const int2 item = tile_item[it];
     const int n = win_count[item.x], start = win_start[item.x];
     const int64_t pos0 = (int64_t)win_tile0[item.x] * 32;
-    const int n_tiles = (n + 31) >> 5;
-    const int64_t row_half = mpad * heads * DHS, tr_half = (int64_t)heads * DH * mpad;
-    const int ki = item.y * 16 + c16;
-    const int64_t kpos = pos0 + ki;
+    const int n_qt = (n + 31) >> 5;
+    const int k0 = item.y * 32;
+    const bool two = n - k0 > 16;
+    const int64_t row_half = mpad * heads * DHS * 2, tr_half = (int64_t)heads * DH * mpad * 2;  // bytes
+    const Lanes<DH> L(g, c16, heads, mpad);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const bf16x8 zf = __builtin_bit_cast(bf16x8, zero4);
 
-    // this wave's 16 keys: B operands (k = channel, column = key)
-    bf16x8 k_hi[KS], k_lo[KS], v_hi[KS], v_lo[KS];
+    // stationary: K and V fragments of the two key groups: B operands (k = channel, column = key)
+    bf16x8 k_hi[2][KS], k_lo[2][KS], v_hi[2][KS], v_lo[2][KS];
+    {
+        const char* kb = reinterpret_cast<const char*>(ws.kp + ((pos0 + k0) * heads + h) * DHS);
+        const char* vb = reinterpret_cast<const char*>(ws.vp + ((pos0 + k0) * heads + h) * DHS);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const bool ok = 32 * s + 8 * g < DHS;
-        const int64_t o = (kpos * heads + h) * DHS + 32 * s + 8 * g;
-        load_frag(ws.kp, o, row_half, ok, &k_hi[s], &k_lo[s]);
-        load_frag(ws.vp, o, row_half, ok, &v_hi[s], &v_lo[s]);
-    }
-    f32x4 dk_acc[NB], dv_acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        dk_acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dv_acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    for (int t = 0; t < n_tiles; ++t) {
-        float pv[8], dsv[8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
-            const int64_t qrow = pos0 + t * 32 + u * 16 + c16;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bool ok = 32 * s + 8 * g < DHS;
-                const int64_t o = (qrow * heads + h) * DHS + 32 * s + 8 * g;
-                bf16x8 a_hi, a_lo;
-                load_frag(ws.qp, o, row_half, ok, &a_hi, &a_lo);
-                s_acc = mfma3(a_hi, a_lo, k_hi[s], k_lo[s], s_acc);   // S[query][key]
-                load_frag(ws.gp, o, row_half, ok, &a_hi, &a_lo);
-                p_acc = mfma3(a_hi, a_lo, v_hi[s], v_lo[s], p_acc);   // dP[query][key]
+                ld2(kb, row_half, L.row[j][s], &k_hi[j][s], &k_lo[j][s]);
+                ld2(vb, row_half, L.row[j][s], &v_hi[j][s], &v_lo[j][s]);
+                if (!L.slice_ok[s]) k_hi[j][s] = k_lo[j][s] = v_hi[j][s] = v_lo[j][s] = zf;
             }
-            // rows of this accumulator: queries 32t + 16u + 4g + r (4 consecutive positions)
-            const int64_t rp = (pos0 + t * 32 + u * 16 + g * 4) * heads + h;
+    }
+    f32x4 dk_acc[2][NB], dv_acc[2][NB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qidx = t * 32 + u * 16 + g * 4 + r;
-                const float lq = ws.lp[rp + (int64_t)r * heads], dl = ws.dp[rp + (int64_t)r * heads];
-                const float p = qidx < n ? __builtin_amdgcn_exp2f(s_acc[r] - lq) : 0.f;
-                pv[u * 4 + r] = p;
-                dsv[u * 4 + r] = p * (p_acc[r] - dl);
-            }
-        }
-        bf16x8 p_hi, p_lo, ds_hi, ds_lo;
-        split_frag(pv, &p_hi, &p_lo);
-        split_frag(dsv, &ds_hi, &ds_lo);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int d = 16 * b + c16;
-            const int64_t o = ((int64_t)h * DH + d) * mpad + pos0 + t * 32 + 8 * g;
-            bf16x8 a_hi, a_lo;
-            load_frag(ws.gt, o, tr_half, d < DH, &a_hi, &a_lo);
-            dv_acc[b] = mfma3(a_hi, a_lo, p_hi, p_lo, dv_acc[b]);     // dV^T[d][key]
-            load_frag(ws.qt, o, tr_half, d < DH, &a_hi, &a_lo);
-            dk_acc[b] = mfma3(a_hi, a_lo, ds_hi, ds_lo, dk_acc[b]);   // dKhat^T[d][key] / ln2
+            dk_acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv_acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    }
+
+    const int64_t qstep = (int64_t)32 * heads * DHS * 2;
+    const char* qb = reinterpret_cast<const char*>(ws.qp + (pos0 * heads + h) * DHS);
+    const char* gb = reinterpret_cast<const char*>(ws.gp + (pos0 * heads + h) * DHS);
+    const char* qtb = reinterpret_cast<const char*>(ws.qt + (int64_t)h * DH * mpad + pos0);
+    const char* gtb = reinterpret_cast<const char*>(ws.gt + (int64_t)h * DH * mpad + pos0);
+    const float* lpb = ws.lp + (int64_t)h * mpad + pos0 + 4 * g;  // + 32 t + 16 u: the accumulator's 4 query rows
+    const float* dpb = ws.dp + (int64_t)h * mpad + pos0 + 4 * g;
+    for (int t = 0; t < n_qt; ++t) {
+        const bool last = t + 1 == n_qt;
+        bf16x8 q_hi[2][KS], q_lo[2][KS], g_hi[2][KS], g_lo[2][KS], qt_hi[NB], qt_lo[NB], gt_hi[NB], gt_lo[NB];
+        f32x4 lq[2], dl[2];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) dk_acc[b] = dk_acc[b] * kLn2;  // Q~ = q_hat * log2e / tau  ->  q_hat / tau = Q~ * ln2
-    const int32_t token = tok[start + (ki < n ? ki : 0)];
-    through_normalise<DH>(k + (int64_t)token * ldk + h * DH, g, dk_acc);
-    if (ki < n) {
-        float* ok_ = dk + (int64_t)token * lddk + h * DH;
-        float* ov = dv + (int64_t)token * lddv + h * DH;
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int s = 0; s < KS; ++s) {
+                ld2(qb + t * qstep, row_half, L.row[u][s], &q_hi[u][s], &q_lo[u][s]);
+                ld2(gb + t * qstep, row_half, L.row[u][s], &g_hi[u][s], &g_lo[u][s]);
+            }
+            lq[u] = *reinterpret_cast<const f32x4*>(lpb + t * 32 + u * 16);
+            dl[u] = *reinterpret_cast<const f32x4*>(dpb + t * 32 + u * 16);
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * b + 4 * g + r;
-                if (d < DH) {
-                    ok_[d] = dk_acc[b][r];
-                    ov[d] = dv_acc[b][r];
+        for (int b = 0; b < NB; ++b) {
+            ld2(qtb + t * 64, tr_half, L.tr[b], &qt_hi[b], &qt_lo[b]);
+            ld2(gtb + t * 64, tr_half, L.tr[b], &gt_hi[b], &gt_lo[b]);
+        }
+        auto group = [&](int j) {
+            float pv[8], dsv[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    s_acc = mfma3(q_hi[u][s], q_lo[u][s], k_hi[j][s], k_lo[j][s], s_acc);  // S[query][key]
+                    p_acc = mfma3(g_hi[u][s], g_lo[u][s], v_hi[j][s], v_lo[j][s], p_acc);  // dP[query][key]
+                }
+                // rows of this accumulator: queries 32t + 16u + 4g + r (4 consecutive positions)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[u][r]);
+                    if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;
+                    pv[u * 4 + r] = p;
+                    dsv[u * 4 + r] = p * (p_acc[r] - dl[u][r]);
                 }
             }
+            bf16x8 p_hi, p_lo, ds_hi, ds_lo;
+            split_frag(pv, &p_hi, &p_lo);
+            split_frag(dsv, &ds_hi, &ds_lo);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                dv_acc[j][b] = mfma3(gt_hi[b], gt_lo[b], p_hi, p_lo, dv_acc[j][b]);    // dV^T[d][key]
+                dk_acc[j][b] = mfma3(qt_hi[b], qt_lo[b], ds_hi, ds_lo, dk_acc[j][b]);  // dKhat^T[d][key] / ln2
+            }
+        };
+        group(0);
+        if (two) group(1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const int ki = k0 + 16 * j + c16;
+        const bool valid = ki < n;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dk_acc[j][b] = dk_acc[j][b] * kLn2;  // Q~ = q_hat * log2e / tau  ->  q_hat / tau = Q~ * ln2
+        const int32_t token = tok[start + (valid ? ki : 0)];
+        through_normalise<DH>(k + (int64_t)token * ldk + h * DH, g, dk_acc[j]);
+        if (valid) {
+            float* ok_ = dk + (int64_t)token * lddk + h * DH;
+            float* ov = dv + (int64_t)token * lddv + h * DH;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int d = 16 * b + 4 * g;
+                if (DH % 4 == 0) {
+                    if (d < DH) {
+                        *reinterpret_cast<f32x4*>(ok_ + d) = dk_acc[j][b];
+                        *reinterpret_cast<f32x4*>(ov + d) = dv_acc[j][b];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (d + r < DH) {
+                            ok_[d + r] = dk_acc[j][b][r];
+                            ov[d + r] = dv_acc[j][b][r];
+                        }
+                }
+            }
+        }
     }
 }
 
@@ -395,15 +494,17 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     hipLaunchKernelGGL(attn_prepare_bwd<DH>, dim3((unsigned)n_tiles), dim3(256), smem, st, q, k, v, ldq, ldk, ldv, dout, out,
                        lse, tok, win_start, win_count, win_tile0, tile_item, heads, mpad, tau, tau_min, ws);
     SEG3D_CHECK_LAUNCH();
-    dim3 grid((unsigned)((n_qg + 3) / 4), (unsigned)heads);
+    (void)qg_item;
+    (void)n_qg;
+    dim3 grid((unsigned)((n_tiles + 3) / 4), (unsigned)heads);
     if (hipMemsetAsync(ws.tau_part, 0, 1024, st) != hipSuccess) return SEG3D_ELAUNCH;
-    hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, qg_item,
-                       n_qg, heads, mpad, tau, tau_min, dq, lddq);
+    hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, tile_item,
+                       n_tiles, heads, mpad, tau, tau_min, dq, lddq);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(256), 0, st, ws.tau_part, dtau);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_kv<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0, qg_item,
-                       n_qg, heads, mpad, dk, lddk, dv, lddv);
+    hipLaunchKernelGGL(attn_bwd_kv<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0, tile_item,
+                       n_tiles, heads, mpad, dk, lddk, dv, lddv);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
