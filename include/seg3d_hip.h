@@ -234,7 +234,9 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
 /* ------------------------------------------------------------------------------------------
  * a12, a22  row-wise normalisation layers on [m, c] features (c multiple of 4).
  * LayerNorm of the post-norm encoder layer (point_transformer_layer.py:289-298), fused with the residual:
- *     y = res + (x - mean_row) * rstd_row * gamma + beta        (res may be NULL; mean/rstd [m] kept for bwd)
+ *     y = res + rowscale_row * ((x - mean_row) * rstd_row * gamma + beta)
+ * res may be NULL; rowscale [m] (the per-row DropPath factor, seg3d/models/layers/drop.py:6-19) may be NULL = 1;
+ * mean/rstd [m] are kept for the backward pass.
  * backward: dx, and dgamma/dbeta [c] (zeroed inside, accumulated with one float atomic per channel per block);
  * the residual's gradient is dy itself.
  * BatchNorm1d (+ residual) (+ ReLU) of the conv blocks / point MLPs (spconv_utils.py:13-32,
@@ -244,11 +246,12 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
  *     seg3d_batchnorm_bwd  g = dy masked by (y > 0) when relu; dres = g (may be NULL);
  *                      dx = gamma*rstd*(g - mean_r(g) - xhat*mean_r(g*xhat)); sums = {dbeta, dgamma}
  */
-int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
-                        int64_t m, int32_t c, float* y, float* mean, float* rstd, void* stream);
+int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                        const float* rowscale, float eps, int64_t m, int32_t c, float* y, float* mean,
+                        float* rstd, void* stream);
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                        const float* gamma, int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta,
-                        void* stream);
+                        const float* gamma, const float* rowscale, int64_t m, int32_t c, float* dx,
+                        float* dgamma, float* dbeta, void* stream);
 int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* stream);
 int seg3d_affine_act(const float* x, const float* res, const float* scale, const float* shift, int32_t relu,
                      int64_t m, int32_t c, float* y, void* stream);

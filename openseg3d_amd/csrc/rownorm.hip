@@ -1,6 +1,7 @@
 // a12 / a22 row-wise normalisation layers on [rows, C] voxel / point features:
 //   * post-norm residual LayerNorm of the SWFormer encoder layer (point_transformer_layer.py:289-298):
-//         y = res + LN(x) * gamma + beta                                   (forward + backward)
+//         y = res + rowscale * (LN(x) * gamma + beta)                      (forward + backward; rowscale =
+//         the per-row stochastic-depth factor of drop.py:6-19, optional)
 //   * BatchNorm1d (+ residual) (+ ReLU) of the sparse-conv blocks and point MLPs (spconv_utils.py:13-32,
 //     pointtransformer.py:47-66, segformer.py:21-76): batch statistics, affine + activation, backward.
 // torch's generic kernels need 75 us (LayerNorm) / 130-170 us (BatchNorm statistics, backward reduce) per call
@@ -41,8 +42,9 @@ __device__ __forceinline__ float group_sum(float v, int p) {
 template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, int64_t m, int c, RowMap rm, float* __restrict__ y,
-                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+                                                          const float* __restrict__ rowscale, float eps, int64_t m, int c,
+                                                          RowMap rm, float* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows_per_wave = 64 / rm.p;
     const int lr = lane / rm.p, lq = lane % rm.p;
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float* __restric
             }
         }
         const float rs = rsqrtf(group_sum(ss, rm.p) * inv_c + eps);
+        const float sc = rowscale && rok ? rowscale[row] : 1.0f;  // per-row stochastic-depth factor
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int q = lq + i * rm.p;
@@ -78,10 +81,10 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float* __restric
                 const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * q);
                 const float4 b = *reinterpret_cast<const float4*>(beta + 4 * q);
                 float4 o;
-                o.x = (v[i].x - mu) * rs * g.x + b.x;
-                o.y = (v[i].y - mu) * rs * g.y + b.y;
-                o.z = (v[i].z - mu) * rs * g.z + b.z;
-                o.w = (v[i].w - mu) * rs * g.w + b.w;
+                o.x = ((v[i].x - mu) * rs * g.x + b.x) * sc;
+                o.y = ((v[i].y - mu) * rs * g.y + b.y) * sc;
+                o.z = ((v[i].z - mu) * rs * g.z + b.z) * sc;
+                o.w = ((v[i].w - mu) * rs * g.w + b.w) * sc;
                 if (res) {
                     const float4 r4 = *reinterpret_cast<const float4*>(res + row * c + 4 * q);
                     o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(const float* __restric
 template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ gamma, int64_t m, int c, RowMap rm,
-                                                          float* __restrict__ dx, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta) {
+                                                          const float* __restrict__ gamma, const float* __restrict__ rowscale,
+                                                          int64_t m, int c, RowMap rm, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
     extern __shared__ float red[];  // [2][c] block partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows_per_wave = 64 / rm.p;
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
         const int64_t row = base + lr;
         const bool rok = row < m;
         const float mu = rok ? mean[row] : 0.f, rs = rok ? rstd[row] : 0.f;
+        const float sc = rowscale && rok ? rowscale[row] : 1.0f;
         float4 xh[ITEMS], gy[ITEMS];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
             xh[i] = gy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rok && q < rm.quads) {
                 const float4 xv = *reinterpret_cast<const float4*>(x + row * c + 4 * q);
-                const float4 dv = *reinterpret_cast<const float4*>(dy + row * c + 4 * q);
+                float4 dv = *reinterpret_cast<const float4*>(dy + row * c + 4 * q);
+                dv.x *= sc; dv.y *= sc; dv.z *= sc; dv.w *= sc;
                 const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * q);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 gy[i] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
@@ -285,25 +290,25 @@ inline bool bad_c(int c) { return c <= 0 || (c & 3) || c > 1024; }
 
 extern "C" {
 
-int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, int64_t m,
-                        int32_t c, float* y, float* mean, float* rstd, void* stream) {
+int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, const float* rowscale,
+                        float eps, int64_t m, int32_t c, float* y, float* mean, float* rstd, void* stream) {
     if (m < 0 || bad_c(c) || c > 512) return SEG3D_EINVAL;
     if (m == 0) return SEG3D_OK;
     if (!x || !gamma || !beta || !y) return SEG3D_EINVAL;
     const RowMap rm = row_map(c);
     const unsigned nb = blocks_for(m, 4 * (64 / rm.p));
     if (rm.items == 1)
-        hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(nb), dim3(kThreads), 0, as_stream(stream), x, res, gamma, beta, eps, m, c,
-                           rm, y, mean, rstd);
+        hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(nb), dim3(kThreads), 0, as_stream(stream), x, res, gamma, beta, rowscale,
+                           eps, m, c, rm, y, mean, rstd);
     else
-        hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(nb), dim3(kThreads), 0, as_stream(stream), x, res, gamma, beta, eps, m, c,
-                           rm, y, mean, rstd);
+        hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(nb), dim3(kThreads), 0, as_stream(stream), x, res, gamma, beta, rowscale,
+                           eps, m, c, rm, y, mean, rstd);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
 
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta, void* stream) {
+                        const float* rowscale, int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta, void* stream) {
     if (m < 0 || bad_c(c) || c > 512 || !dgamma || !dbeta) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
@@ -315,11 +320,11 @@ int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
     if (nb > 512) nb = 512;
     const size_t smem = (size_t)2 * c * sizeof(float);
     if (rm.items == 1)
-        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, m, c, rm, dx,
-                           dgamma, dbeta);
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c, rm,
+                           dx, dgamma, dbeta);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, m, c, rm, dx,
-                           dgamma, dbeta);
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c, rm,
+                           dx, dgamma, dbeta);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

@@ -330,43 +330,47 @@ def linear(x, weight, bias=None, exact=False):
 
 # ------------------------------------------------------------------------------------------ a12/a22 norms
 class _LayerNormResidualFn(torch.autograd.Function):
-    """y = res + LayerNorm(x) (res optional)."""
+    """y = res + rowscale * LayerNorm(x) (res, rowscale optional; rowscale [rows] carries no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, rowscale):
         x = _f32c(x)
         m, c = x.shape
         y = torch.empty_like(x)
         mean = torch.empty((m,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((m,), dtype=torch.float32, device=x.device)
         r = None if res is None else _f32c(res)
-        _lib.call("seg3d_layernorm_fwd", _ptr(x), _ptr(r), _ptr(gamma), _ptr(beta), float(eps), m, c, _ptr(y),
+        rs = None if rowscale is None else _f32c(rowscale.reshape(-1))
+        _lib.call("seg3d_layernorm_fwd", _ptr(x), _ptr(r), _ptr(gamma), _ptr(beta), _ptr(rs), float(eps), m, c, _ptr(y),
                   _ptr(mean), _ptr(rstd), _stream())
-        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.save_for_backward(x, mean, rstd, gamma, rs)
         ctx.has_res = res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, rstd, gamma = ctx.saved_tensors
+        x, mean, rstd, gamma, rs = ctx.saved_tensors
         dy = _f32c(dy)
         m, c = x.shape
         dx = torch.empty_like(x)
         dg = torch.empty((c,), dtype=torch.float32, device=x.device)
         db = torch.empty((c,), dtype=torch.float32, device=x.device)
-        _lib.call("seg3d_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), m, c, _ptr(dx),
+        _lib.call("seg3d_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rs), m, c, _ptr(dx),
                   _ptr(dg), _ptr(db), _stream())
-        return dx, (dy if ctx.has_res else None), dg, db, None
+        return dx, (dy if ctx.has_res else None), dg, db, None, None
 
 
-def layer_norm_residual(x, res, ln):
-    """res + ln(x) for an nn.LayerNorm over the last dim of [rows, C] (C % 4 == 0, C <= 512)."""
+def layer_norm_residual(x, res, ln, rowscale=None):
+    """res + rowscale * ln(x) for an nn.LayerNorm over the last dim of [rows, C] (C % 4 == 0, C <= 512);
+    rowscale [rows] is the per-row DropPath factor (mask / keep_prob), None = 1."""
     c = x.shape[1]
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and c % 4 == 0 and c <= 512
             and ln.elementwise_affine and ln.bias is not None):
         y = ln(x)
+        if rowscale is not None:
+            y = y * rowscale.reshape(-1, 1)
         return y if res is None else res + y
-    return _LayerNormResidualFn.apply(x, res, ln.weight, ln.bias, ln.eps)
+    return _LayerNormResidualFn.apply(x, res, ln.weight, ln.bias, ln.eps, rowscale)
 
 
 class _BatchNormActFn(torch.autograd.Function):

@@ -152,15 +152,20 @@ class MLP(nn.Module):
         return x
 
 
+def drop_path_scale(x, p):
+    """Per-row stochastic-depth factor mask / keep_prob, [rows] (seg3d/models/layers/drop.py:6-19)."""
+    keep = 1.0 - p
+    mask = x.new_empty((x.shape[0],)).bernoulli_(keep)
+    if keep > 0.0:
+        mask.div_(keep)
+    return mask
+
+
 def drop_path(x, p, training):
     """Per-row stochastic depth (seg3d/models/layers/drop.py:6-19)."""
     if p == 0.0 or not training:
         return x
-    keep = 1.0 - p
-    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-    if keep > 0.0:
-        mask.div_(keep)
-    return x * mask
+    return x * drop_path_scale(x, p).reshape((x.shape[0],) + (1,) * (x.dim() - 1))
 
 
 class EncoderLayer(nn.Module):
@@ -179,8 +184,9 @@ class EncoderLayer(nn.Module):
         if self.drop_path_rate == 0.0 or not self.training:  # fused residual + LayerNorm
             x = ops.layer_norm_residual(a, x, self.norm1)
             return ops.layer_norm_residual(self.mlp(x), x, self.norm2)
-        x = x + drop_path(ops.layer_norm_residual(a, None, self.norm1), self.drop_path_rate, True)
-        return x + drop_path(ops.layer_norm_residual(self.mlp(x), None, self.norm2), self.drop_path_rate, True)
+        # stochastic depth rides in the same pass: x + mask/keep * LN(.)
+        x = ops.layer_norm_residual(a, x, self.norm1, rowscale=drop_path_scale(x, self.drop_path_rate))
+        return ops.layer_norm_residual(self.mlp(x), x, self.norm2, rowscale=drop_path_scale(x, self.drop_path_rate))
 
 
 class SWFormerBlock(nn.Module):

@@ -38,6 +38,34 @@ def test_layernorm_residual_forward_backward(m, c, with_res):
         assert float((got.cpu().double() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("m,c", [(1000, 48), (3001, 192)])
+def test_layernorm_residual_with_drop_path_scale(m, c):
+    """x + mask/keep * LN(a): the per-row stochastic-depth factor rides in the fused pass (drop.py:6-19)."""
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m)
+    a, x, g = torch.randn(m, c), torch.randn(m, c), torch.randn(m, c)
+    scale = (torch.rand(m) < 0.8).float() / 0.8
+    ln = nn.LayerNorm(c)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(c))
+        ln.bias.copy_(0.1 * torch.randn(c))
+    ref_ln = nn.LayerNorm(c).double()
+    ref_ln.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    ar, xr = a.double().requires_grad_(), x.double().requires_grad_()
+    yr = xr + ref_ln(ar) * scale.double()[:, None]
+    yr.backward(g.double())
+    ln = ln.to(dev)
+    ag, xg = a.to(dev).requires_grad_(), x.to(dev).requires_grad_()
+    y = ops.layer_norm_residual(ag, xg, ln, rowscale=scale.to(dev))
+    y.backward(g.to(dev))
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    assert float((ag.grad.cpu().double() - ar.grad).abs().max()) < 2e-5
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 1e-6
+    for got, ref in ((ln.weight.grad, ref_ln.weight.grad), (ln.bias.grad, ref_ln.bias.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("m,c", [(1000, 48), (4099, 96), (300, 256), (70001, 64), (2, 32)])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("with_res", [True, False])

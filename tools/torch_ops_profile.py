@@ -1,0 +1,37 @@
+"""torch.profiler view of one training step: which aten ops launch the small elementwise kernels (GPU box only)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from openseg3d_amd import batch as B, config, scene, segformer
+
+dev = torch.device("cuda:0")
+cfg = config.default_cfg()
+ds = config.DatasetSpec(cfg)
+model = segformer.build_segmentor(cfg, ds).to(dev).train()
+opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+b = B.make_batch([scene.make_scene(0)], ds.voxel_size, ds.point_cloud_range)
+ce = torch.nn.functional.cross_entropy
+
+
+def step():
+    n = b["points"].shape[0]
+    labels = torch.arange(n, device=dev) % 22
+    opt.zero_grad(set_to_none=True)
+    res = model(b)
+    loss = (ce(res["point_out"], labels) + ce(res["voxel_out"], labels[:1].expand(res["voxel_out"].shape[0]))
+            + 0.4 * ce(res["aux_voxel_out"], labels[:1].expand(res["aux_voxel_out"].shape[0])))
+    loss.backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    step()
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=False).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=60))
+print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=50,
+                                                   max_src_column_width=110))
