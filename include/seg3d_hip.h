@@ -242,7 +242,11 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
  * BatchNorm1d (+ residual) (+ ReLU) of the conv blocks / point MLPs (spconv_utils.py:13-32,
  * pointtransformer.py:47-66, segformer.py:21-76):
  *     seg3d_colstats   sums[0..c) = sum_r (x - x[0]), sums[c..2c) = sum_r (x - x[0])^2   (shifted, cancellation-free)
- *     seg3d_affine_act y = act(x * scale + shift (+ res)), scale/shift [c] folded from the statistics by the caller
+ *     seg3d_batchnorm_stats  colstats + one finalize pass: stats [6][c] = {scratch, scratch, mean, rstd (biased
+ *                      variance), scale = gamma*rstd, shift = beta - mean*scale}; running_mean / running_var (may be
+ *                      NULL) updated in place with `momentum` (unbiased variance), as torch.nn.BatchNorm1d does
+ *     seg3d_affine_act y = act(x * scale + shift (+ res)), scale/shift [c] as produced above (or folded from the
+ *                      running statistics by the caller in eval mode)
  *     seg3d_batchnorm_bwd  g = dy masked by (y > 0) when relu; dres = g (may be NULL);
  *                      dx = gamma*rstd*(g - mean_r(g) - xhat*mean_r(g*xhat)); sums = {dbeta, dgamma}
  */
@@ -253,6 +257,8 @@ int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         const float* gamma, const float* rowscale, int64_t m, int32_t c, float* dx,
                         float* dgamma, float* dbeta, void* stream);
 int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* stream);
+int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const float* gamma, const float* beta,
+                          float momentum, float* running_mean, float* running_var, float* stats, void* stream);
 int seg3d_affine_act(const float* x, const float* res, const float* scale, const float* shift, int32_t relu,
                      int64_t m, int32_t c, float* y, void* stream);
 int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,

@@ -84,10 +84,13 @@ __global__ __launch_bounds__(256) void attn_prepare_bwd(const float* __restrict_
     for (int which = 0; which < 4; ++which) {  // 0 q, 1 k, 2 v, 3 dO
         const float* src = which == 0 ? q : which == 1 ? k : which == 2 ? v : dout;
         const int ld = which == 0 ? ldq : which == 1 ? ldk : which == 2 ? ldv : c;
-        for (int e = tid; e < 32 * c; e += 256) {
-            const int row = e / c, col = e - row * c;
+        for (int e = tid; e < 8 * c; e += 256) {  // 16-B row pieces (c and every ld are multiples of 4)
+            const int row = e / (c / 4), col = 4 * (e - row * (c / 4));
             const int t = trow[row];
-            buf[row * cp + col] = t >= 0 ? src[(int64_t)t * ld + col] : 0.f;
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0) x4 = *reinterpret_cast<const float4*>(src + (int64_t)t * ld + col);
+            float* b4 = buf + row * cp + col;
+            b4[0] = x4.x; b4[1] = x4.y; b4[2] = x4.z; b4[3] = x4.w;
         }
         __syncthreads();
         for (int e = tid; e < 32 * heads; e += 256) {
@@ -116,26 +119,38 @@ __global__ __launch_bounds__(256) void attn_prepare_bwd(const float* __restrict_
             }
         }
         __syncthreads();
+        // 16-B stores: one item = 8 consecutive stored channels of one (row, head)
         __bf16* rm = which == 0 ? ws.qp : which == 1 ? ws.kp : which == 2 ? ws.vp : ws.gp;
-        for (int e = tid; e < 32 * heads * DHS; e += 256) {
-            const int ds = e % DHS, h = (e / DHS) % heads, row = e / (DHS * heads);
-            const float x = ds < DH ? buf[row * cp + h * DH + ds] * rn[row * heads + h] : 0.f;
-            __bf16 hi, lo;
-            split1(x, &hi, &lo);
-            const int64_t o = ((pos0 + row) * heads + h) * DHS + ds;
-            rm[o] = hi;
-            rm[row_half + o] = lo;
+        constexpr int CH8 = DHS / 8;
+        for (int e = tid; e < 32 * heads * CH8; e += 256) {
+            const int c8 = e % CH8, h = (e / CH8) % heads, row = e / (CH8 * heads);
+            const float r = rn[row * heads + h];
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = 8 * c8 + j < DH ? buf[row * cp + h * DH + 8 * c8 + j] * r : 0.f;
+            bf16x8 hi, lo;
+            split_frag(x, &hi, &lo);
+            const int64_t o = ((pos0 + row) * heads + h) * DHS + 8 * c8;
+            *reinterpret_cast<bf16x8*>(rm + o) = hi;
+            *reinterpret_cast<bf16x8*>(rm + row_half + o) = lo;
         }
         if (which != 2) {
+            // transposed: one item = the 8 token slots 8g .. 8g+7 of one channel row (tokens 4g..4g+3, 16+4g..16+4g+3)
             __bf16* tr = which == 0 ? ws.qt : which == 1 ? ws.kt : ws.gt;
-            for (int e = tid; e < 32 * c; e += 256) {
-                const int row = e & 31, ch = e >> 5;
+            for (int e = tid; e < 4 * c; e += 256) {
+                const int sg = e & 3, ch = e >> 2;
                 const int h = ch / DH;
-                __bf16 hi, lo;
-                split1(buf[row * cp + ch] * rn[row * heads + h], &hi, &lo);
-                const int64_t o = (int64_t)ch * mpad + pos0 + perm_slot(row);
-                tr[o] = hi;
-                tr[tr_half + o] = lo;
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = j < 4 ? 4 * sg + j : 12 + 4 * sg + j;
+                    x[j] = buf[row * cp + ch] * rn[row * heads + h];
+                }
+                bf16x8 hi, lo;
+                split_frag(x, &hi, &lo);
+                const int64_t o = (int64_t)ch * mpad + pos0 + 8 * sg;
+                *reinterpret_cast<bf16x8*>(tr + o) = hi;
+                *reinterpret_cast<bf16x8*>(tr + tr_half + o) = lo;
             }
         }
         __syncthreads();
@@ -543,6 +558,10 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
         !qg_item || m < 0 || n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !dq ||
         !dk || !dv || !dtau || !workspace)
         return SEG3D_EINVAL;
+    if (((ldq | ldk | ldv | lddq | lddk | lddv) & 3) ||
+        ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+          reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15))
+        return SEG3D_EINVAL;  // rows are gathered / stored in 16-B pieces
     const size_t need = bwd_bytes(n_tiles, heads, dh);
     if (need == 0) return SEG3D_EINVAL;
     if (workspace_bytes < need) return SEG3D_EWORKSPACE;

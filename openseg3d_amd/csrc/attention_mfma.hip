@@ -88,10 +88,13 @@ __global__ __launch_bounds__(256) void attn_prepare_fwd(const float* __restrict_
     for (int which = 0; which < 3; ++which) {
         const float* src = which == 0 ? q : which == 1 ? k : v;
         const int ld = which == 0 ? ldq : which == 1 ? ldk : ldv;
-        for (int e = tid; e < 32 * c; e += 256) {
-            const int row = e / c, col = e - row * c;
+        for (int e = tid; e < 8 * c; e += 256) {  // 16-B row pieces (c and every ld are multiples of 4)
+            const int row = e / (c / 4), col = 4 * (e - row * (c / 4));
             const int t = trow[row];
-            buf[row * cp + col] = t >= 0 ? src[(int64_t)t * ld + col] : 0.f;
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0) x4 = *reinterpret_cast<const float4*>(src + (int64_t)t * ld + col);
+            float* b4 = buf + row * cp + col;
+            b4[0] = x4.x; b4[1] = x4.y; b4[2] = x4.z; b4[3] = x4.w;
         }
         __syncthreads();
         if (which < 2) {
@@ -106,26 +109,47 @@ __global__ __launch_bounds__(256) void attn_prepare_fwd(const float* __restrict_
                 rn[e] = (which == 0 ? qscale : 1.0f) / fmaxf(sqrtf(s), kNormEps);
             }
             __syncthreads();
+            // 16-B stores: one item = 8 consecutive stored channels of one (row, head)
             __bf16* dst = which == 0 ? qp : kp;
             const int64_t half = mpad * heads * DHS;  // hi block then lo block
-            for (int e = tid; e < 32 * heads * DHS; e += 256) {
-                const int ds = e % DHS, h = (e / DHS) % heads, row = e / (DHS * heads);
-                const float x = ds < DH ? buf[row * cp + h * DH + ds] * rn[row * heads + h] : 0.f;
-                __bf16 hi, lo;
-                split1(x, &hi, &lo);
-                const int64_t o = ((pos0 + row) * heads + h) * DHS + ds;
-                dst[o] = hi;
-                dst[half + o] = lo;
+            constexpr int CH8 = DHS / 8;
+            for (int e = tid; e < 32 * heads * CH8; e += 256) {
+                const int c8 = e % CH8, h = (e / CH8) % heads, row = e / (CH8 * heads);
+                const float r = rn[row * heads + h];
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = 8 * c8 + j < DH ? buf[row * cp + h * DH + 8 * c8 + j] * r : 0.f;
+                u32x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = pack_bf16(x[2 * j], x[2 * j + 1]);
+                    hi[j] = w;
+                    lo[j] = pack_bf16(x[2 * j] - __builtin_bit_cast(float, w << 16),
+                                      x[2 * j + 1] - __builtin_bit_cast(float, w & 0xFFFF0000u));
+                }
+                const int64_t o = ((pos0 + row) * heads + h) * DHS + 8 * c8;
+                *reinterpret_cast<u32x4*>(dst + o) = hi;
+                *reinterpret_cast<u32x4*>(dst + half + o) = lo;
             }
         } else {
+            // transposed: one item = the 8 token slots 8g .. 8g+7 of one channel row (tokens 4g..4g+3, 16+4g..16+4g+3)
             const int64_t half = (int64_t)heads * DH * mpad;
-            for (int e = tid; e < 32 * c; e += 256) {
-                const int row = e & 31, ch = e >> 5;  // ch = h*DH + d
-                __bf16 hi, lo;
-                split1(buf[row * cp + ch], &hi, &lo);
-                const int64_t o = (int64_t)ch * mpad + pos0 + perm_slot(row);
-                vt[o] = hi;
-                vt[half + o] = lo;
+            for (int e = tid; e < 4 * c; e += 256) {
+                const int sg = e & 3, ch = e >> 2;
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = buf[(j < 4 ? 4 * sg + j : 12 + 4 * sg + j) * cp + ch];
+                u32x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = pack_bf16(x[2 * j], x[2 * j + 1]);
+                    hi[j] = w;
+                    lo[j] = pack_bf16(x[2 * j] - __builtin_bit_cast(float, w << 16),
+                                      x[2 * j + 1] - __builtin_bit_cast(float, w & 0xFFFF0000u));
+                }
+                const int64_t o = (int64_t)ch * mpad + pos0 + 8 * sg;
+                *reinterpret_cast<u32x4*>(vt + o) = hi;
+                *reinterpret_cast<u32x4*>(vt + half + o) = lo;
             }
         }
         __syncthreads();
@@ -389,6 +413,9 @@ extern "C" int seg3d_window_attn_fwd(const float* q, const float* k, const float
     if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) return SEG3D_OK;
     if (!q || !k || !v || !tok || !win_start || !win_count || !win_tile0 || !tile_item || !qg_item || m < 0 ||
         n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !out || !workspace)
+        return SEG3D_EINVAL;
+    // rows are gathered in 16-B pieces
+    if (((ldq | ldk | ldv) & 3) || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15))
         return SEG3D_EINVAL;
     const size_t need = attn_mfma_workspace_bytes(n_tiles, heads, dh);
     if (need == 0) return SEG3D_EINVAL;

@@ -277,6 +277,30 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
     }
 }
 
+// batch statistics -> everything the forward / backward passes and the running buffers need, one thread per channel
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const float* __restrict__ x, int64_t m, int c, float eps,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float momentum, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ stats) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= c) return;
+    const float inv_m = 1.0f / (float)m;
+    const float d = stats[i] * inv_m;              // mean of (x - x[0])
+    const float mean = x[i] + d;
+    const float var = fmaxf(stats[c + i] * inv_m - d * d, 0.0f);  // biased
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float scale = gamma[i] * rstd;
+    stats[2 * c + i] = mean;
+    stats[3 * c + i] = rstd;
+    stats[4 * c + i] = scale;
+    stats[5 * c + i] = beta[i] - mean * scale;
+    if (running_mean) {
+        running_mean[i] = running_mean[i] * (1.0f - momentum) + mean * momentum;
+        const float unbiased = m > 1 ? var * ((float)m / (float)(m - 1)) : var;
+        running_var[i] = running_var[i] * (1.0f - momentum) + unbiased * momentum;
+    }
+}
+
 inline unsigned blocks_for(int64_t work_items, int per_block) {
     int64_t b = ceil_div64(work_items, per_block);
     if (b > kMaxBlocks) b = kMaxBlocks;
@@ -340,6 +364,17 @@ int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums /*[2][c]: s
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(kThreads), (size_t)2 * c * sizeof(float), st, x, nullptr,
                        nullptr, nullptr, nullptr, 0, m, c, sums);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const float* gamma, const float* beta,
+                          float momentum, float* running_mean, float* running_var, float* stats /*[6][c]*/, void* stream) {
+    if (m <= 0 || bad_c(c) || !x || !gamma || !beta || !stats || (running_mean && !running_var)) return SEG3D_EINVAL;
+    const int rc = seg3d_colstats(x, m, c, stats, stream);
+    if (rc != SEG3D_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + kThreads - 1) / kThreads)), dim3(kThreads), 0, as_stream(stream),
+                       x, m, c, eps, gamma, beta, momentum, running_mean, running_var, stats);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

@@ -377,11 +377,9 @@ class _BatchNormActFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over rows (+ residual) (+ ReLU); statistics are computed in forward."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, mean, rstd, relu):
+    def forward(ctx, x, res, gamma, beta, mean, rstd, scale, shift, relu):
         x = _f32c(x)
         m, c = x.shape
-        scale = gamma * rstd
-        shift = beta - mean * scale
         y = torch.empty_like(x)
         r = None if res is None else _f32c(res)
         _lib.call("seg3d_affine_act", _ptr(x), _ptr(r), _ptr(scale), _ptr(shift), int(relu), m, c, _ptr(y), _stream())
@@ -399,7 +397,7 @@ class _BatchNormActFn(torch.autograd.Function):
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         _lib.call("seg3d_batchnorm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), int(ctx.relu),
                   m, c, _ptr(dx), _ptr(dres), _ptr(sums), _stream())
-        return dx, dres, sums[1], sums[0], None, None, None
+        return dx, dres, sums[1], sums[0], None, None, None, None, None
 
 
 def batch_norm_act(x, bn, relu=True, res=None):
@@ -417,19 +415,17 @@ def batch_norm_act(x, bn, relu=True, res=None):
     if use_batch:
         xc = _f32c(x)
         m = xc.shape[0]
-        with torch.no_grad():
-            sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
-            _lib.call("seg3d_colstats", _ptr(xc), m, c, _ptr(sums), _stream())
-            d = sums[0] / m
-            mean = xc[0] + d
-            var = (sums[1] / m - d * d).clamp_(min=0.0)
-            rstd = torch.rsqrt(var + bn.eps)
-            if bn.training and bn.track_running_stats:
+        with torch.no_grad():  # statistics, folded affine and running buffers in one call (two small launches)
+            stats = torch.empty((6, c), dtype=torch.float32, device=x.device)
+            track = bn.training and bn.track_running_stats
+            mom = 0.0
+            if track:
                 bn.num_batches_tracked += 1
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var * (m / (m - 1)), alpha=mom)
-        return _BatchNormActFn.apply(xc, res, bn.weight, bn.bias, mean, rstd, bool(relu))
+            _lib.call("seg3d_batchnorm_stats", _ptr(xc), m, c, float(bn.eps), _ptr(bn.weight), _ptr(bn.bias), float(mom),
+                      _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None, _ptr(stats),
+                      _stream())
+        return _BatchNormActFn.apply(xc, res, bn.weight, bn.bias, stats[2], stats[3], stats[4], stats[5], bool(relu))
     with torch.no_grad():
         scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
