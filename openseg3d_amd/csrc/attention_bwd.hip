@@ -16,6 +16,12 @@
 #include "attn_common.hpp"
 
 size_t attn_mfma_workspace_bytes(int n_tiles, int heads, int dh);  // attention_mfma.hip
+bool attn_use_small(int heads, int dh);                            // attention_mfma.hip
+int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
+                          const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
+                          const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads, int dh,
+                          const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
+                          float* dtau, void* workspace, hipStream_t st);  // attention_small.hip
 
 namespace {
 
@@ -562,6 +568,12 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
         ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
           reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15))
         return SEG3D_EINVAL;  // rows are gathered / stored in 16-B pieces
+    if (attn_use_small(heads, dh)) {
+        if (workspace_bytes < 1024) return SEG3D_EWORKSPACE;
+        return attn_small_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
+                                     heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace,
+                                     as_stream(stream));
+    }
     const size_t need = bwd_bytes(n_tiles, heads, dh);
     if (need == 0) return SEG3D_EINVAL;
     if (workspace_bytes < need) return SEG3D_EWORKSPACE;

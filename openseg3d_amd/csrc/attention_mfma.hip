@@ -18,9 +18,20 @@
 //
 // Algorithmic FLOPs: 4*C*sum_w n_w^2 per layer; executed MFMA FLOPs are 3x that (split) plus
 // tile padding.  Error: ~2^-16 relative per product (same budget as the sparse convs).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
+
+// attention_small.hip: exact-fp32 vector-ALU path for narrow heads (dh = 6, 12)
+bool attn_small_supported(int heads, int dh);
+int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+                          const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles,
+                          int heads, int dh, const float* tau, float tau_min, float* out, float* lse, hipStream_t st);
+bool attn_use_small(int heads, int dh) {
+    static const bool mfma_only = getenv("SEG3D_ATTN_MFMA_ONLY") != nullptr;  // A/B switch for profiling
+    return !mfma_only && attn_small_supported(heads, dh);
+}
 
 namespace {
 
@@ -414,6 +425,13 @@ extern "C" int seg3d_window_attn_fwd(const float* q, const float* k, const float
     if (!q || !k || !v || !tok || !win_start || !win_count || !win_tile0 || !tile_item || !qg_item || m < 0 ||
         n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !out || !workspace)
         return SEG3D_EINVAL;
+    if (attn_use_small(heads, dh)) {
+        if (((ldq | ldk | ldv) & 3) ||
+            ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15))
+            return SEG3D_EINVAL;
+        return attn_small_fwd_launch(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, tile_item, n_tiles, heads, dh, tau,
+                                     tau_min, out, lse, as_stream(stream));
+    }
     // rows are gathered in 16-B pieces
     if (((ldq | ldk | ldv) & 3) || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15))
         return SEG3D_EINVAL;

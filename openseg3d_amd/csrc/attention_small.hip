@@ -1,0 +1,402 @@
+// a19-a21 for narrow heads (dh = 6, 12: SWFormer stages 1-2, C = 48 / 96): exact-fp32 vector-ALU window attention.
+//
+// At these stages the windows hold 13-60 voxels on average and a head is 6 or 12 channels wide: a 16x16x32 MFMA
+// tile would be 3/4 (dh = 6) or 5/8 (dh = 12) padding, and the matrix-core path spends its time on one dependent
+// chain of small loads per (32-token tile, head) wave.  Here one thread owns one (token, head) pair and keeps its
+// whole dh-vector in registers; the streamed side of a window (keys / queries) goes through LDS 32 tokens at a time,
+// every LDS read is a broadcast (all lanes of a half-wave share the head), nothing crosses lanes, and the
+// arithmetic is plain fp32 -- no operand split, no prepare pass, no workspace.
+//   forward : thread (query i, head h): scores of 32 keys in registers, online softmax, o += p * v
+//   pass Q  : thread (query i, head h): dq_hat += ds * k_hat / tau, dtau += ds * s          (ds = p (dp - delta))
+//   pass KV : thread (key j, head h)  : dv += p * dO, dk_hat += ds * q_hat / tau
+// with the gradient through x_hat = x / max(|x|, eps) applied to the thread's own vector at the end.
+// Work items are the (window, 32-token tile) list of seg3d_window_partition; block = 32 tokens x heads threads.
+#include "attn_common.hpp"
+
+namespace {
+
+using namespace attn;
+
+template <int DH>
+struct Vec {
+    float v[DH];
+};
+
+// DH floats from a 8-B (DH = 6) / 16-B (DH = 12) aligned address
+template <int DH>
+__device__ __forceinline__ Vec<DH> load_vec(const float* p) {
+    Vec<DH> r;
+    if (DH % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < DH / 4; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            r.v[4 * i] = t[0]; r.v[4 * i + 1] = t[1]; r.v[4 * i + 2] = t[2]; r.v[4 * i + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < DH / 2; ++i) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * i);
+            r.v[2 * i] = t[0]; r.v[2 * i + 1] = t[1];
+        }
+    }
+    return r;
+}
+
+template <int DH>
+__device__ __forceinline__ void store_vec(float* p, const Vec<DH>& r) {
+    if (DH % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < DH / 4; ++i)
+            *reinterpret_cast<f32x4*>(p + 4 * i) = (f32x4){r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < DH / 2; ++i) *reinterpret_cast<f32x2*>(p + 2 * i) = (f32x2){r.v[2 * i], r.v[2 * i + 1]};
+    }
+}
+
+template <int DH>
+__device__ __forceinline__ float dot(const Vec<DH>& a, const Vec<DH>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) s = fmaf(a.v[d], b.v[d], s);
+    return s;
+}
+
+// x -> x / max(|x|, eps) * scale; returns |x|
+template <int DH>
+__device__ __forceinline__ float normalise(Vec<DH>* x, float scale) {
+    const float len = sqrtf(dot(*x, *x));
+    const float r = scale / fmaxf(len, kNormEps);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) x->v[d] *= r;
+    return len;
+}
+
+// gradient through x_hat = x / max(|x|, eps): g (w.r.t. x_hat) -> g (w.r.t. x), cosine_msa.py:152-153
+template <int DH>
+__device__ __forceinline__ void through_normalise(const Vec<DH>& x_raw, Vec<DH>* g) {
+    const float len = sqrtf(dot(x_raw, x_raw));
+    const float rinv = 1.0f / fmaxf(len, kNormEps);
+    if (len < kNormEps) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) g->v[d] *= rinv;
+        return;
+    }
+    float proj = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) proj = fmaf(x_raw.v[d] * rinv, g->v[d], proj);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) g->v[d] = (g->v[d] - x_raw.v[d] * rinv * proj) * rinv;
+}
+
+constexpr int kTile = 32;
+
+// ------------------------------------------------------------------ forward
+template <int DH>
+__global__ __launch_bounds__(256) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int ldq, int ldk, int ldv,
+                                                      const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
+                                                      const int32_t* __restrict__ win_count, const int2* __restrict__ tile_item,
+                                                      int heads, const float* __restrict__ tau, float tau_min,
+                                                      float* __restrict__ out, float* __restrict__ lse) {
+    extern __shared__ float smem[];  // k_hat [32][heads*DH], v [32][heads*DH]
+    const int c = heads * DH;
+    float* kbuf = smem;
+    float* vbuf = smem + kTile * c;
+    const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
+    const int2 item = tile_item[blockIdx.x];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int qi = item.y * kTile + i;
+    const int32_t qtok = qi < n ? tok[start + qi] : -1;
+    Vec<DH> qn;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) qn.v[d] = 0.f;
+    if (qtok >= 0) {
+        qn = load_vec<DH>(q + (int64_t)qtok * ldq + h * DH);
+        normalise<DH>(&qn, kLog2e / fmaxf(tau[0], tau_min));
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    Vec<DH> o;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o.v[d] = 0.f;
+
+    for (int t0 = 0; t0 < n; t0 += kTile) {
+        __syncthreads();
+        {  // stage key row t0 + i, head h
+            const int kj = t0 + i;
+            Vec<DH> kk, vv;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) kk.v[d] = vv.v[d] = 0.f;
+            if (kj < n) {
+                const int32_t kt = tok[start + kj];
+                kk = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
+                vv = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
+                normalise<DH>(&kk, 1.0f);
+            }
+            store_vec<DH>(kbuf + i * c + h * DH, kk);
+            store_vec<DH>(vbuf + i * c + h * DH, vv);
+        }
+        __syncthreads();
+        const int nk = n - t0 < kTile ? n - t0 : kTile;
+        float s[kTile];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kTile; ++j) {
+            const Vec<DH> kk = load_vec<DH>(kbuf + j * c + h * DH);
+            s[j] = j < nk ? dot(qn, kk) : -INFINITY;
+            tmax = fmaxf(tmax, s[j]);
+        }
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o.v[d] *= alpha;
+#pragma unroll
+        for (int j = 0; j < kTile; ++j) {
+            const float p = __builtin_amdgcn_exp2f(s[j] - m_new);
+            psum += p;
+            const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) o.v[d] = fmaf(p, vv.v[d], o.v[d]);
+        }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+    }
+    if (qtok >= 0) {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o.v[d] *= inv;
+        store_vec<DH>(out + (int64_t)qtok * c + h * DH, o);
+        if (lse) lse[(int64_t)qtok * heads + h] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
+    }
+}
+
+// ------------------------------------------------------------------ backward, pass Q: dq, dtau
+template <int DH>
+__global__ __launch_bounds__(256) void attn_small_bwd_q(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, int ldq, int ldk, int ldv,
+                                                        const float* __restrict__ out, const float* __restrict__ dout,
+                                                        const float* __restrict__ lse, const int32_t* __restrict__ tok,
+                                                        const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
+                                                        const int2* __restrict__ tile_item, int heads,
+                                                        const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
+                                                        int lddq, float* __restrict__ tau_part) {
+    extern __shared__ float smem[];
+    const int c = heads * DH;
+    float* kbuf = smem;
+    float* vbuf = smem + kTile * c;
+    __shared__ float tau_red[8];
+    const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
+    const int2 item = tile_item[blockIdx.x];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int qi = item.y * kTile + i;
+    const int32_t qtok = qi < n ? tok[start + qi] : -1;
+    const float tau_c = fmaxf(tau[0], tau_min);
+    Vec<DH> q_raw, qn, go, acc;
+    float l2 = 0.f, delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) q_raw.v[d] = qn.v[d] = go.v[d] = acc.v[d] = 0.f;
+    if (qtok >= 0) {
+        q_raw = load_vec<DH>(q + (int64_t)qtok * ldq + h * DH);
+        qn = q_raw;
+        normalise<DH>(&qn, kLog2e / tau_c);
+        go = load_vec<DH>(dout + (int64_t)qtok * c + h * DH);
+        const Vec<DH> oo = load_vec<DH>(out + (int64_t)qtok * c + h * DH);
+        delta = dot(go, oo);
+        l2 = lse[(int64_t)qtok * heads + h] * kLog2e;
+    }
+    float tau_acc = 0.f;
+    for (int t0 = 0; t0 < n; t0 += kTile) {
+        __syncthreads();
+        {
+            const int kj = t0 + i;
+            Vec<DH> kk, vv;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) kk.v[d] = vv.v[d] = 0.f;
+            if (kj < n) {
+                const int32_t kt = tok[start + kj];
+                kk = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
+                vv = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
+                normalise<DH>(&kk, 1.0f);
+            }
+            store_vec<DH>(kbuf + i * c + h * DH, kk);
+            store_vec<DH>(vbuf + i * c + h * DH, vv);
+        }
+        __syncthreads();
+        const int nk = n - t0 < kTile ? n - t0 : kTile;
+#pragma unroll 8
+        for (int j = 0; j < kTile; ++j) {
+            const Vec<DH> kk = load_vec<DH>(kbuf + j * c + h * DH);
+            const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
+            const float s = dot(qn, kk);
+            const float p = j < nk ? __builtin_amdgcn_exp2f(s - l2) : 0.f;
+            const float ds = p * (dot(go, vv) - delta);
+            tau_acc = fmaf(ds, s, tau_acc);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) acc.v[d] = fmaf(ds, kk.v[d], acc.v[d]);
+        }
+    }
+    if (qtok >= 0) {
+        const float inv_tau = 1.0f / tau_c;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc.v[d] *= inv_tau;
+        through_normalise<DH>(q_raw, &acc);
+        store_vec<DH>(dq + (int64_t)qtok * lddq + h * DH, acc);
+    } else {
+        tau_acc = 0.f;
+    }
+    // d/dtau: s_nat = s2 * ln2 = c / tau  ->  dL/dtau = -sum(ds * s_nat) / tau   (zero while tau is clamped)
+    for (int off = 32; off > 0; off >>= 1) tau_acc += __shfl_xor(tau_acc, off, SEG3D_WAVE);
+    if ((threadIdx.x & 63) == 0) tau_red[threadIdx.x >> 6] = tau_acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && tau[0] > tau_min) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += tau_red[w];
+        if (t != 0.f) atomicAdd(&tau_part[blockIdx.x & 255], -t * kLn2 / tau_c);
+    }
+}
+
+// ------------------------------------------------------------------ backward, pass KV: dk, dv
+template <int DH>
+__global__ __launch_bounds__(256) void attn_small_bwd_kv(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, int ldq, int ldk, int ldv,
+                                                         const float* __restrict__ out, const float* __restrict__ dout,
+                                                         const float* __restrict__ lse, const int32_t* __restrict__ tok,
+                                                         const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
+                                                         const int2* __restrict__ tile_item, int heads,
+                                                         const float* __restrict__ tau, float tau_min, float* __restrict__ dk,
+                                                         int lddk, float* __restrict__ dv, int lddv) {
+    extern __shared__ float smem[];  // q~ [32][c], dO [32][c], (L, delta) [32][heads][2]
+    const int c = heads * DH;
+    float* qbuf = smem;
+    float* gbuf = smem + kTile * c;
+    float* lbuf = smem + 2 * kTile * c;
+    const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
+    const int2 item = tile_item[blockIdx.x];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int kj = item.y * kTile + i;
+    const int32_t ktok = kj < n ? tok[start + kj] : -1;
+    const float tau_c = fmaxf(tau[0], tau_min);
+    Vec<DH> k_raw, kn, vv, dk_acc, dv_acc;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) k_raw.v[d] = kn.v[d] = vv.v[d] = dk_acc.v[d] = dv_acc.v[d] = 0.f;
+    if (ktok >= 0) {
+        k_raw = load_vec<DH>(k + (int64_t)ktok * ldk + h * DH);
+        kn = k_raw;
+        normalise<DH>(&kn, 1.0f);
+        vv = load_vec<DH>(v + (int64_t)ktok * ldv + h * DH);
+    }
+    for (int t0 = 0; t0 < n; t0 += kTile) {
+        __syncthreads();
+        {  // stage query row t0 + i, head h
+            const int qi = t0 + i;
+            Vec<DH> qq, gg;
+            float l2 = 0.f, delta = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) qq.v[d] = gg.v[d] = 0.f;
+            if (qi < n) {
+                const int32_t qt = tok[start + qi];
+                qq = load_vec<DH>(q + (int64_t)qt * ldq + h * DH);
+                normalise<DH>(&qq, kLog2e / tau_c);
+                gg = load_vec<DH>(dout + (int64_t)qt * c + h * DH);
+                const Vec<DH> oo = load_vec<DH>(out + (int64_t)qt * c + h * DH);
+                delta = dot(gg, oo);
+                l2 = lse[(int64_t)qt * heads + h] * kLog2e;
+            }
+            store_vec<DH>(qbuf + i * c + h * DH, qq);
+            store_vec<DH>(gbuf + i * c + h * DH, gg);
+            *reinterpret_cast<f32x2*>(lbuf + (i * heads + h) * 2) = (f32x2){l2, delta};
+        }
+        __syncthreads();
+        const int nq = n - t0 < kTile ? n - t0 : kTile;
+#pragma unroll 8
+        for (int j = 0; j < kTile; ++j) {
+            const Vec<DH> qq = load_vec<DH>(qbuf + j * c + h * DH);
+            const Vec<DH> gg = load_vec<DH>(gbuf + j * c + h * DH);
+            const f32x2 ld = *reinterpret_cast<const f32x2*>(lbuf + (j * heads + h) * 2);
+            const float s = dot(qq, kn);
+            const float p = j < nq ? __builtin_amdgcn_exp2f(s - ld[0]) : 0.f;
+            const float ds = p * (dot(gg, vv) - ld[1]);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) {
+                dv_acc.v[d] = fmaf(p, gg.v[d], dv_acc.v[d]);
+                dk_acc.v[d] = fmaf(ds, qq.v[d], dk_acc.v[d]);
+            }
+        }
+    }
+    if (ktok >= 0) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) dk_acc.v[d] *= kLn2;  // q~ = q_hat * log2e / tau  ->  q_hat / tau = q~ * ln2
+        through_normalise<DH>(k_raw, &dk_acc);
+        store_vec<DH>(dk + (int64_t)ktok * lddk + h * DH, dk_acc);
+        store_vec<DH>(dv + (int64_t)ktok * lddv + h * DH, dv_acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void tau_reduce_small(const float* __restrict__ part, float* __restrict__ dtau) {
+    float v = part[threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, SEG3D_WAVE);
+    __shared__ float w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) dtau[0] += w[0] + w[1] + w[2] + w[3];
+}
+
+template <int DH>
+int run_small_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+                  const int32_t* win_start, const int32_t* win_count, const int2* tile_item, int n_tiles, int heads,
+                  const float* tau, float tau_min, float* out, float* lse, hipStream_t st) {
+    const size_t smem = (size_t)2 * kTile * heads * DH * sizeof(float);
+    hipLaunchKernelGGL(attn_small_fwd<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem, st, q, k, v, ldq, ldk, ldv, tok,
+                       win_start, win_count, tile_item, heads, tau, tau_min, out, lse);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+template <int DH>
+int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
+                  const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
+                  const int32_t* win_count, const int2* tile_item, int n_tiles, int heads, const float* tau, float tau_min,
+                  float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part,
+                  hipStream_t st) {
+    if (hipMemsetAsync(tau_part, 0, 1024, st) != hipSuccess) return SEG3D_ELAUNCH;
+    const size_t smem_q = (size_t)2 * kTile * heads * DH * sizeof(float);
+    hipLaunchKernelGGL(attn_small_bwd_q<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem_q, st, q, k, v, ldq, ldk, ldv,
+                       out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dq, lddq, tau_part);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tau_reduce_small, dim3(1), dim3(256), 0, st, tau_part, dtau);
+    SEG3D_CHECK_LAUNCH();
+    const size_t smem_kv = smem_q + (size_t)kTile * heads * 2 * sizeof(float);
+    hipLaunchKernelGGL(attn_small_bwd_kv<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem_kv, st, q, k, v, ldq, ldk, ldv,
+                       out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dk, lddk, dv, lddv);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+}  // namespace
+
+// used by seg3d_window_attn_fwd / _bwd (attention_mfma.hip, attention_bwd.hip); heads <= 8, dh in {6, 12}
+bool attn_small_supported(int heads, int dh) { return (dh == 6 || dh == 12) && heads >= 1 && heads <= 8; }
+
+int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+                          const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles,
+                          int heads, int dh, const float* tau, float tau_min, float* out, float* lse, hipStream_t st) {
+    const int2* ti = reinterpret_cast<const int2*>(tile_item);
+    if (dh == 6)
+        return run_small_fwd<6>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, ti, n_tiles, heads, tau, tau_min, out, lse, st);
+    return run_small_fwd<12>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, ti, n_tiles, heads, tau, tau_min, out, lse, st);
+}
+
+int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
+                          const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
+                          const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads, int dh,
+                          const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
+                          float* dtau, void* workspace, hipStream_t st) {
+    const int2* ti = reinterpret_cast<const int2*>(tile_item);
+    float* tau_part = static_cast<float*>(workspace);  // 256 floats
+    if (dh == 6)
+        return run_small_bwd<6>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
+                                tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, st);
+    return run_small_bwd<12>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
+                             tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, st);
+}
