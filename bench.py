@@ -112,10 +112,12 @@ def conv_roofline(model, batch, dev):
     attn_tf = a_flop / a_ms / 1e9 if a_ms > 0 else 0.0
     global ATTENTION_REPORT
     ATTENTION_REPORT = {
-        "bound": "mfma", "kernel": "attn_prepare_fwd + attn_core_fwd (18 encoder layers of one forward)",
+        "bound": "mfma", "kernel": "window attention of one forward, 18 encoder layers: attn_prepare_fwd + attn_core_fwd "
+                                   "(dh 24/48, split-bf16 MFMA) and attn_small_fwd (dh 6/12, exact-fp32 vector ALU)",
         "achieved": round(attn_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(attn_tf / 2500.0, 5),
-        "note": "algorithmic 4*C*sum(n_w^2) FLOPs per layer / HIP-event time; the kernels execute 3 bf16 MFMAs "
-                "per product (split-bf16) on 16x32-token tiles, so executed MFMA FLOPs are >= 3x the algorithmic",
+        "note": "algorithmic 4*C*sum(n_w^2) FLOPs per layer / HIP-event time; the MFMA kernels execute 3 bf16 MFMAs "
+                "per product (split-bf16) on 32x32-token tiles, so executed MFMA FLOPs are >= 3x the algorithmic; "
+                "the two narrow-head stages do not use the matrix cores at all",
         "layers": len(attn_records), "gflop_per_forward": round(a_flop / 1e9, 2), "ms_per_forward": round(a_ms, 3)}
     pairs_cache, tot_bytes, tot_ms = {}, 0.0, 0.0
     per_layer = []
