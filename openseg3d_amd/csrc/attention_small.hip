@@ -17,10 +17,20 @@ namespace {
 
 using namespace attn;
 
+// dh-vector of one (token, head) as float pairs: every multiply-add below is a v_pk_fma_f32 (two fp32 FMAs per lane
+// per instruction), which is what these kernels are bound by
 template <int DH>
 struct Vec {
-    float v[DH];
+    f32x2 p[DH / 2];
 };
+
+template <int DH>
+__device__ __forceinline__ Vec<DH> zero_vec() {
+    Vec<DH> r;
+#pragma unroll
+    for (int i = 0; i < DH / 2; ++i) r.p[i] = (f32x2){0.f, 0.f};
+    return r;
+}
 
 // DH floats from a 8-B (DH = 6) / 16-B (DH = 12) aligned address
 template <int DH>
@@ -30,14 +40,12 @@ __device__ __forceinline__ Vec<DH> load_vec(const float* p) {
 #pragma unroll
         for (int i = 0; i < DH / 4; ++i) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * i);
-            r.v[4 * i] = t[0]; r.v[4 * i + 1] = t[1]; r.v[4 * i + 2] = t[2]; r.v[4 * i + 3] = t[3];
+            r.p[2 * i] = (f32x2){t[0], t[1]};
+            r.p[2 * i + 1] = (f32x2){t[2], t[3]};
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < DH / 2; ++i) {
-            const f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * i);
-            r.v[2 * i] = t[0]; r.v[2 * i + 1] = t[1];
-        }
+        for (int i = 0; i < DH / 2; ++i) r.p[i] = *reinterpret_cast<const f32x2*>(p + 2 * i);
     }
     return r;
 }
@@ -47,28 +55,41 @@ __device__ __forceinline__ void store_vec(float* p, const Vec<DH>& r) {
     if (DH % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < DH / 4; ++i)
-            *reinterpret_cast<f32x4*>(p + 4 * i) = (f32x4){r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]};
+            *reinterpret_cast<f32x4*>(p + 4 * i) = (f32x4){r.p[2 * i][0], r.p[2 * i][1], r.p[2 * i + 1][0], r.p[2 * i + 1][1]};
     } else {
 #pragma unroll
-        for (int i = 0; i < DH / 2; ++i) *reinterpret_cast<f32x2*>(p + 2 * i) = (f32x2){r.v[2 * i], r.v[2 * i + 1]};
+        for (int i = 0; i < DH / 2; ++i) *reinterpret_cast<f32x2*>(p + 2 * i) = r.p[i];
     }
 }
 
 template <int DH>
 __device__ __forceinline__ float dot(const Vec<DH>& a, const Vec<DH>& b) {
-    float s = 0.f;
+    f32x2 s = {0.f, 0.f};
 #pragma unroll
-    for (int d = 0; d < DH; ++d) s = fmaf(a.v[d], b.v[d], s);
-    return s;
+    for (int i = 0; i < DH / 2; ++i) s = __builtin_elementwise_fma(a.p[i], b.p[i], s);
+    return s[0] + s[1];
 }
 
-// x -> x / max(|x|, eps) * scale; returns |x|
+// y += a * x
 template <int DH>
-__device__ __forceinline__ float normalise(Vec<DH>* x, float scale) {
-    const float len = sqrtf(dot(*x, *x));
-    const float r = scale / fmaxf(len, kNormEps);
+__device__ __forceinline__ void axpy(float a, const Vec<DH>& x, Vec<DH>* y) {
+    const f32x2 aa = {a, a};
 #pragma unroll
-    for (int d = 0; d < DH; ++d) x->v[d] *= r;
+    for (int i = 0; i < DH / 2; ++i) y->p[i] = __builtin_elementwise_fma(aa, x.p[i], y->p[i]);
+}
+
+template <int DH>
+__device__ __forceinline__ void scale(float a, Vec<DH>* y) {
+    const f32x2 aa = {a, a};
+#pragma unroll
+    for (int i = 0; i < DH / 2; ++i) y->p[i] = y->p[i] * aa;
+}
+
+// x -> x / max(|x|, eps) * scale_to; returns |x|
+template <int DH>
+__device__ __forceinline__ float normalise(Vec<DH>* x, float scale_to) {
+    const float len = sqrtf(dot(*x, *x));
+    scale<DH>(scale_to / fmaxf(len, kNormEps), x);
     return len;
 }
 
@@ -78,22 +99,21 @@ __device__ __forceinline__ void through_normalise(const Vec<DH>& x_raw, Vec<DH>*
     const float len = sqrtf(dot(x_raw, x_raw));
     const float rinv = 1.0f / fmaxf(len, kNormEps);
     if (len < kNormEps) {
-#pragma unroll
-        for (int d = 0; d < DH; ++d) g->v[d] *= rinv;
+        scale<DH>(rinv, g);
         return;
     }
-    float proj = 0.f;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) proj = fmaf(x_raw.v[d] * rinv, g->v[d], proj);
-#pragma unroll
-    for (int d = 0; d < DH; ++d) g->v[d] = (g->v[d] - x_raw.v[d] * rinv * proj) * rinv;
+    Vec<DH> xh = x_raw;
+    scale<DH>(rinv, &xh);
+    const float proj = dot(xh, *g);
+    axpy<DH>(-proj, xh, g);
+    scale<DH>(rinv, g);
 }
 
 constexpr int kTile = 32;
 
 // ------------------------------------------------------------------ forward
 template <int DH>
-__global__ __launch_bounds__(256) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, int ldq, int ldk, int ldv,
                                                       const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                       const int32_t* __restrict__ win_count, const int2* __restrict__ tile_item,
@@ -108,64 +128,66 @@ __global__ __launch_bounds__(256) void attn_small_fwd(const float* __restrict__ 
     const int n = win_count[item.x], start = win_start[item.x];
     const int qi = item.y * kTile + i;
     const int32_t qtok = qi < n ? tok[start + qi] : -1;
-    Vec<DH> qn;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) qn.v[d] = 0.f;
+    Vec<DH> qn = zero_vec<DH>();
     if (qtok >= 0) {
         qn = load_vec<DH>(q + (int64_t)qtok * ldq + h * DH);
         normalise<DH>(&qn, kLog2e / fmaxf(tau[0], tau_min));
     }
     float m_run = -INFINITY, l_run = 0.f;
-    Vec<DH> o;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) o.v[d] = 0.f;
+    Vec<DH> o = zero_vec<DH>();
 
+    // raw k / v rows of the tile to come are fetched while the current tile is multiplied
+    Vec<DH> k_next, v_next;
+    auto fetch_kv = [&](int t0) {
+        const int kj = t0 + i;
+        k_next = v_next = zero_vec<DH>();
+        if (kj < n) {
+            const int32_t kt = tok[start + kj];
+            k_next = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
+            v_next = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
+        }
+    };
+    fetch_kv(0);
     for (int t0 = 0; t0 < n; t0 += kTile) {
         __syncthreads();
         {  // stage key row t0 + i, head h
-            const int kj = t0 + i;
-            Vec<DH> kk, vv;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) kk.v[d] = vv.v[d] = 0.f;
-            if (kj < n) {
-                const int32_t kt = tok[start + kj];
-                kk = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
-                vv = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
-                normalise<DH>(&kk, 1.0f);
-            }
+            Vec<DH> kk = k_next;
+            normalise<DH>(&kk, 1.0f);
             store_vec<DH>(kbuf + i * c + h * DH, kk);
-            store_vec<DH>(vbuf + i * c + h * DH, vv);
+            store_vec<DH>(vbuf + i * c + h * DH, v_next);
         }
         __syncthreads();
+        if (t0 + kTile < n) fetch_kv(t0 + kTile);
         const int nk = n - t0 < kTile ? n - t0 : kTile;
-        float s[kTile];
-        float tmax = -INFINITY;
+        // online softmax in groups of 8 keys (keeps the register footprint at 8 scores)
+#pragma unroll 1
+        for (int j0 = 0; j0 < kTile; j0 += 8) {
+            if (j0 >= nk) break;
+            float s[8];
+            float gmax = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < kTile; ++j) {
-            const Vec<DH> kk = load_vec<DH>(kbuf + j * c + h * DH);
-            s[j] = j < nk ? dot(qn, kk) : -INFINITY;
-            tmax = fmaxf(tmax, s[j]);
+            for (int j = 0; j < 8; ++j) {
+                const Vec<DH> kk = load_vec<DH>(kbuf + (j0 + j) * c + h * DH);
+                s[j] = j0 + j < nk ? dot(qn, kk) : -INFINITY;
+                gmax = fmaxf(gmax, s[j]);
+            }
+            const float m_new = fmaxf(m_run, gmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.f;
+            scale<DH>(alpha, &o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(s[j] - m_new);
+                psum += p;
+                const Vec<DH> vv = load_vec<DH>(vbuf + (j0 + j) * c + h * DH);
+                axpy<DH>(p, vv, &o);
+            }
+            l_run = fmaf(l_run, alpha, psum);
+            m_run = m_new;
         }
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) o.v[d] *= alpha;
-#pragma unroll
-        for (int j = 0; j < kTile; ++j) {
-            const float p = __builtin_amdgcn_exp2f(s[j] - m_new);
-            psum += p;
-            const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
-#pragma unroll
-            for (int d = 0; d < DH; ++d) o.v[d] = fmaf(p, vv.v[d], o.v[d]);
-        }
-        l_run = fmaf(l_run, alpha, psum);
-        m_run = m_new;
     }
     if (qtok >= 0) {
-        const float inv = 1.0f / l_run;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) o.v[d] *= inv;
+        scale<DH>(1.0f / l_run, &o);
         store_vec<DH>(out + (int64_t)qtok * c + h * DH, o);
         if (lse) lse[(int64_t)qtok * heads + h] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
     }
@@ -173,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd(const float* __restrict__ 
 
 // ------------------------------------------------------------------ backward, pass Q: dq, dtau
 template <int DH>
-__global__ __launch_bounds__(256) void attn_small_bwd_q(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, int ldq, int ldk, int ldv,
                                                         const float* __restrict__ out, const float* __restrict__ dout,
                                                         const float* __restrict__ lse, const int32_t* __restrict__ tok,
@@ -192,10 +214,8 @@ __global__ __launch_bounds__(256) void attn_small_bwd_q(const float* __restrict_
     const int qi = item.y * kTile + i;
     const int32_t qtok = qi < n ? tok[start + qi] : -1;
     const float tau_c = fmaxf(tau[0], tau_min);
-    Vec<DH> q_raw, qn, go, acc;
+    Vec<DH> q_raw = zero_vec<DH>(), qn = zero_vec<DH>(), go = zero_vec<DH>(), acc = zero_vec<DH>();
     float l2 = 0.f, delta = 0.f;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) q_raw.v[d] = qn.v[d] = go.v[d] = acc.v[d] = 0.f;
     if (qtok >= 0) {
         q_raw = load_vec<DH>(q + (int64_t)qtok * ldq + h * DH);
         qn = q_raw;
@@ -206,25 +226,29 @@ __global__ __launch_bounds__(256) void attn_small_bwd_q(const float* __restrict_
         l2 = lse[(int64_t)qtok * heads + h] * kLog2e;
     }
     float tau_acc = 0.f;
+    Vec<DH> k_next, v_next;
+    auto fetch_kv = [&](int t0) {
+        const int kj = t0 + i;
+        k_next = v_next = zero_vec<DH>();
+        if (kj < n) {
+            const int32_t kt = tok[start + kj];
+            k_next = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
+            v_next = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
+        }
+    };
+    fetch_kv(0);
     for (int t0 = 0; t0 < n; t0 += kTile) {
         __syncthreads();
         {
-            const int kj = t0 + i;
-            Vec<DH> kk, vv;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) kk.v[d] = vv.v[d] = 0.f;
-            if (kj < n) {
-                const int32_t kt = tok[start + kj];
-                kk = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
-                vv = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
-                normalise<DH>(&kk, 1.0f);
-            }
+            Vec<DH> kk = k_next;
+            normalise<DH>(&kk, 1.0f);
             store_vec<DH>(kbuf + i * c + h * DH, kk);
-            store_vec<DH>(vbuf + i * c + h * DH, vv);
+            store_vec<DH>(vbuf + i * c + h * DH, v_next);
         }
         __syncthreads();
+        if (t0 + kTile < n) fetch_kv(t0 + kTile);
         const int nk = n - t0 < kTile ? n - t0 : kTile;
-#pragma unroll 8
+#pragma unroll 4
         for (int j = 0; j < kTile; ++j) {
             const Vec<DH> kk = load_vec<DH>(kbuf + j * c + h * DH);
             const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
@@ -232,14 +256,11 @@ __global__ __launch_bounds__(256) void attn_small_bwd_q(const float* __restrict_
             const float p = j < nk ? __builtin_amdgcn_exp2f(s - l2) : 0.f;
             const float ds = p * (dot(go, vv) - delta);
             tau_acc = fmaf(ds, s, tau_acc);
-#pragma unroll
-            for (int d = 0; d < DH; ++d) acc.v[d] = fmaf(ds, kk.v[d], acc.v[d]);
+            axpy<DH>(ds, kk, &acc);
         }
     }
     if (qtok >= 0) {
-        const float inv_tau = 1.0f / tau_c;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) acc.v[d] *= inv_tau;
+        scale<DH>(1.0f / tau_c, &acc);
         through_normalise<DH>(q_raw, &acc);
         store_vec<DH>(dq + (int64_t)qtok * lddq + h * DH, acc);
     } else {
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_q(const float* __restrict_
 
 // ------------------------------------------------------------------ backward, pass KV: dk, dv
 template <int DH>
-__global__ __launch_bounds__(256) void attn_small_bwd_kv(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void attn_small_bwd_kv(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int ldq, int ldk, int ldv,
                                                          const float* __restrict__ out, const float* __restrict__ dout,
                                                          const float* __restrict__ lse, const int32_t* __restrict__ tok,
@@ -277,39 +298,41 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kv(const float* __restrict
     const int kj = item.y * kTile + i;
     const int32_t ktok = kj < n ? tok[start + kj] : -1;
     const float tau_c = fmaxf(tau[0], tau_min);
-    Vec<DH> k_raw, kn, vv, dk_acc, dv_acc;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) k_raw.v[d] = kn.v[d] = vv.v[d] = dk_acc.v[d] = dv_acc.v[d] = 0.f;
+    Vec<DH> k_raw = zero_vec<DH>(), kn = zero_vec<DH>(), vv = zero_vec<DH>(), dk_acc = zero_vec<DH>(), dv_acc = zero_vec<DH>();
     if (ktok >= 0) {
         k_raw = load_vec<DH>(k + (int64_t)ktok * ldk + h * DH);
         kn = k_raw;
         normalise<DH>(&kn, 1.0f);
         vv = load_vec<DH>(v + (int64_t)ktok * ldv + h * DH);
     }
+    Vec<DH> q_next, g_next, o_next;
+    float lse_next = 0.f;
+    auto fetch_q = [&](int t0) {
+        const int qi = t0 + i;
+        q_next = g_next = o_next = zero_vec<DH>();
+        lse_next = 0.f;
+        if (qi < n) {
+            const int32_t qt = tok[start + qi];
+            q_next = load_vec<DH>(q + (int64_t)qt * ldq + h * DH);
+            g_next = load_vec<DH>(dout + (int64_t)qt * c + h * DH);
+            o_next = load_vec<DH>(out + (int64_t)qt * c + h * DH);
+            lse_next = lse[(int64_t)qt * heads + h];
+        }
+    };
+    fetch_q(0);
     for (int t0 = 0; t0 < n; t0 += kTile) {
         __syncthreads();
-        {  // stage query row t0 + i, head h
-            const int qi = t0 + i;
-            Vec<DH> qq, gg;
-            float l2 = 0.f, delta = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) qq.v[d] = gg.v[d] = 0.f;
-            if (qi < n) {
-                const int32_t qt = tok[start + qi];
-                qq = load_vec<DH>(q + (int64_t)qt * ldq + h * DH);
-                normalise<DH>(&qq, kLog2e / tau_c);
-                gg = load_vec<DH>(dout + (int64_t)qt * c + h * DH);
-                const Vec<DH> oo = load_vec<DH>(out + (int64_t)qt * c + h * DH);
-                delta = dot(gg, oo);
-                l2 = lse[(int64_t)qt * heads + h] * kLog2e;
-            }
+        {  // stage query row t0 + i, head h (all-zero rows past n: p is masked below)
+            Vec<DH> qq = q_next;
+            normalise<DH>(&qq, kLog2e / tau_c);
             store_vec<DH>(qbuf + i * c + h * DH, qq);
-            store_vec<DH>(gbuf + i * c + h * DH, gg);
-            *reinterpret_cast<f32x2*>(lbuf + (i * heads + h) * 2) = (f32x2){l2, delta};
+            store_vec<DH>(gbuf + i * c + h * DH, g_next);
+            *reinterpret_cast<f32x2*>(lbuf + (i * heads + h) * 2) = (f32x2){lse_next * kLog2e, dot(g_next, o_next)};
         }
         __syncthreads();
+        if (t0 + kTile < n) fetch_q(t0 + kTile);
         const int nq = n - t0 < kTile ? n - t0 : kTile;
-#pragma unroll 8
+#pragma unroll 4
         for (int j = 0; j < kTile; ++j) {
             const Vec<DH> qq = load_vec<DH>(qbuf + j * c + h * DH);
             const Vec<DH> gg = load_vec<DH>(gbuf + j * c + h * DH);
@@ -317,16 +340,12 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kv(const float* __restrict
             const float s = dot(qq, kn);
             const float p = j < nq ? __builtin_amdgcn_exp2f(s - ld[0]) : 0.f;
             const float ds = p * (dot(gg, vv) - ld[1]);
-#pragma unroll
-            for (int d = 0; d < DH; ++d) {
-                dv_acc.v[d] = fmaf(p, gg.v[d], dv_acc.v[d]);
-                dk_acc.v[d] = fmaf(ds, qq.v[d], dk_acc.v[d]);
-            }
+            axpy<DH>(p, gg, &dv_acc);
+            axpy<DH>(ds, qq, &dk_acc);
         }
     }
     if (ktok >= 0) {
-#pragma unroll
-        for (int d = 0; d < DH; ++d) dk_acc.v[d] *= kLn2;  // q~ = q_hat * log2e / tau  ->  q_hat / tau = q~ * ln2
+        scale<DH>(kLn2, &dk_acc);  // q~ = q_hat * log2e / tau  ->  q_hat / tau = q~ * ln2
         through_normalise<DH>(k_raw, &dk_acc);
         store_vec<DH>(dk + (int64_t)ktok * lddk + h * DH, dk_acc);
         store_vec<DH>(dv + (int64_t)ktok * lddv + h * DH, dv_acc);
