@@ -149,6 +149,20 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
 size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int32_t cout);
 int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
                        float* db /* [cout] or NULL */, void* workspace, size_t workspace_bytes, void* stream);
+/* Batched split-bf16 packing: one launch for every conv / Linear weight whose pack is stale (in training all of
+ * them, twice: W for forward, W^T for the input gradient).  `jobs` is a DEVICE array of n_jobs records sorted by
+ * first_block; job i covers blocks [first_block_i, first_block_{i+1}) of 256 packed elements each
+ * (ceil(packed_bytes / 2 / 256) blocks); dst as for seg3d_spconv_pack_weight (flags bit2 set) /
+ * seg3d_linear_pack_weight.  kk = 27 (conv, weight [Cout,27,Cin]) or 1 (Linear, weight [Cout,Cin]). */
+typedef struct {
+  const float* src;     /* weight in the reference layout */
+  void* dst;            /* packed stream */
+  int32_t cin, cout;    /* of the weight as stored */
+  int32_t kk, transpose, flip, reserved;
+  int64_t first_block;
+} seg3d_pack_job;       /* 48 bytes */
+int seg3d_pack_weights_batched(const void* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
+
 /* a6, a22  forward / input gradient of the same layers: y[m, cout] = x[m, cin] . W^T + bias, as the
  * single-offset case of the split-bf16 gather-GEMM kernel (W fragments staged through LDS once per
  * 128-row tile).  weight is torch's [cout, cin]; transpose=1 packs W itself as the operand, i.e.

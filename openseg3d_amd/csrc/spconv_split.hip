@@ -77,6 +77,50 @@ __global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict
     wp[t] = h ? (__bf16)(v - (float)hi) : hi;
 }
 
+// One launch for many weights (all conv and Linear packs of a training step: the weights change every optimizer
+// step and every layer needs W and W^T).  jobs are sorted by first_block; a block finds its job by bisection.
+struct PackJob {
+    const float* src;
+    __bf16* dst;
+    int32_t cin_src, cout_src, kk, transpose, flip, reserved;
+    int64_t first_block;
+};
+static_assert(sizeof(PackJob) == 48, "PackJob layout is part of the C ABI (seg3d_pack_weights_batched)");
+
+__global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {  // last job with first_block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int64_t)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackJob jb = jobs[lo];
+    const int cin_op = jb.transpose ? jb.cout_src : jb.cin_src;
+    const int cout_op = jb.transpose ? jb.cin_src : jb.cout_src;
+    const int cb_n = (cin_op + 31) / 32, nb_n = cout_op / 16;
+    const int64_t total = (int64_t)jb.kk * cb_n * nb_n * 1024;
+    const int64_t t = ((int64_t)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (t >= total) return;
+    int64_t r = t;
+    const int j = (int)(r & 7); r >>= 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int h = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % nb_n); r /= nb_n;
+    const int cb = (int)(r % cb_n); r /= cb_n;
+    const int kp = (int)r;
+    const int ci_op = cb * 32 + (lane >> 4) * 8 + j;
+    const int co_op = nb * 16 + (lane & 15);
+    float v = 0.f;
+    if (ci_op < cin_op) {
+        const int k = jb.flip ? jb.kk - 1 - kp : kp;
+        const int ci = jb.transpose ? co_op : ci_op;
+        const int co = jb.transpose ? ci_op : co_op;
+        v = jb.src[((int64_t)co * jb.kk + k) * jb.cin_src + ci];
+    }
+    const __bf16 hi16 = (__bf16)v;
+    jb.dst[t] = h ? (__bf16)(v - (float)hi16) : hi16;
+}
+
 template <int NBT, int RB, bool DENSE>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
@@ -335,6 +379,15 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
 // cosine_msa.py:58-63,403).  A Linear layer is the single-offset case of the kernel above (identity neighbour
 // table): W fragments staged through LDS once per 128-row tile, rows streamed with 32-B loads, split-bf16 MFMA.
 extern "C" {
+
+int seg3d_pack_weights_batched(const void* jobs, int32_t n_jobs, int64_t total_blocks, void* stream) {
+    if (n_jobs < 0 || total_blocks < 0 || total_blocks > 0x7FFFFFFF || (n_jobs > 0 && !jobs)) return SEG3D_EINVAL;
+    if (n_jobs == 0 || total_blocks == 0) return SEG3D_OK;
+    hipLaunchKernelGGL(pack_weights_batched, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                       static_cast<const PackJob*>(jobs), (int)n_jobs);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
 
 size_t seg3d_linear_packed_bytes(int32_t cin, int32_t cout, int32_t transpose) {
     if (cin <= 0 || cout <= 0) return 0;

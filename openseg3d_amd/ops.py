@@ -10,6 +10,7 @@ The names exported for reference compatibility mirror ``seg3d.ops`` (seg3d/ops/_
 vfe.py:25 and se_layer.py:25.
 """
 import ctypes
+import weakref
 import os
 
 import torch
@@ -185,6 +186,79 @@ def _precision_flag():
     raise _lib.Seg3dError(f"SEG3D_CONV_PRECISION must be 'bf16x3' or 'fp32', got {CONV_PRECISION!r}")
 
 
+# ---- pack registry: every (parameter [slice], operand form) that has been packed once is remembered; when a pack
+# is requested and the parameter has changed since (every optimizer step in training), ALL stale packs are
+# refreshed by one seg3d_pack_weights_batched launch instead of ~220 small ones per step.
+class _PackJob:
+    __slots__ = ("owner", "src_ptr", "out", "cin", "cout", "kk", "transpose", "flip", "version", "blocks")
+
+
+_PACK_JOBS = {}
+_PACK_DESC = {}  # tuple of job keys -> (device descriptor tensor, total blocks)
+
+
+def _cached_pack(weight, kk, transpose, flip):
+    """Split-bf16 pack of a contiguous fp32 parameter (or row slice of one) through the registry."""
+    owner = weight._base if weight._base is not None else weight
+    key = (id(owner), weight.storage_offset(), tuple(weight.shape), kk, transpose, flip)
+    job = _PACK_JOBS.get(key)
+    if job is None or job.owner() is not owner or job.src_ptr != weight.data_ptr():
+        cout, cin = weight.shape[0], weight.shape[-1]
+        job = _PackJob()
+        job.owner, job.src_ptr = weakref.ref(owner), weight.data_ptr()
+        job.cin, job.cout, job.kk, job.transpose, job.flip = cin, cout, kk, int(transpose), int(flip)
+        nbytes = (_lib.query("seg3d_spconv_packed_bytes", cin, cout, 4 | job.transpose) if kk == 27
+                  else _lib.query("seg3d_linear_packed_bytes", cin, cout, job.transpose))
+        job.out = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+        job.blocks = (nbytes // 2 + 255) // 256
+        job.version = -1
+        _PACK_JOBS[key] = job
+        _PACK_DESC.clear()
+    if job.version != owner._version:
+        _refresh_packs(weight.device)
+    return job.out
+
+
+def _refresh_packs(device):
+    stale, dead = [], []
+    for key, job in _PACK_JOBS.items():
+        owner = job.owner()
+        if owner is None:
+            dead.append(key)
+        elif job.version != owner._version and job.out.device == device:
+            stale.append((key, job, owner))
+    for key in dead:
+        del _PACK_JOBS[key]
+    if dead:
+        _PACK_DESC.clear()
+    if not stale:
+        return
+    ident = tuple(k for k, _, _ in stale)
+    hit = _PACK_DESC.get(ident)
+    if hit is None:
+        import numpy as np
+        rec = np.zeros((len(stale),), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("cin", "<i4"), ("cout", "<i4"),
+                                                       ("kk", "<i4"), ("transpose", "<i4"), ("flip", "<i4"),
+                                                       ("reserved", "<i4"), ("first_block", "<i8")]))
+        first = 0
+        for i, (_, job, _) in enumerate(stale):
+            rec[i] = (job.src_ptr, job.out.data_ptr(), job.cin, job.cout, job.kk, job.transpose, job.flip, 0, first)
+            first += job.blocks
+        desc = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        hit = (desc, first)
+        if len(_PACK_DESC) > 8:
+            _PACK_DESC.clear()
+        _PACK_DESC[ident] = hit
+    _lib.call("seg3d_pack_weights_batched", _ptr(hit[0]), len(stale), hit[1], _stream())
+    for _, job, owner in stale:
+        job.version = owner._version
+
+
+def _registry_ok(weight):
+    return (CONV_PRECISION == "bf16x3" and weight.is_cuda and weight.dtype == torch.float32 and weight.is_contiguous()
+            and not weight.is_inference())
+
+
 class PackedWeight:
     __slots__ = ("data", "flags")
 
@@ -194,9 +268,11 @@ class PackedWeight:
 
 def pack_weight(weight, flags):
     """weight [Cout,3,3,3,Cin] (or [Cout,27,Cin]) -> MFMA B-fragment stream for seg3d_spconv_fwd."""
+    flags = int(flags) | _precision_flag()
+    if _registry_ok(weight) and (weight if weight._base is None else weight._base).is_leaf and weight.shape[-1] % 16 == 0:
+        return PackedWeight(_cached_pack(weight, 27, flags & 1, (flags >> 1) & 1), flags)
     w = _f32c(weight)
     cout, cin = w.shape[0], w.shape[-1]
-    flags = int(flags) | _precision_flag()
     nbytes = _lib.query("seg3d_spconv_packed_bytes", cin, cout, flags)
     out = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
     _lib.call("seg3d_spconv_pack_weight", _ptr(w), cin, cout, flags, _ptr(out), _stream())
@@ -252,20 +328,15 @@ def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None):
 
 # ------------------------------------------------------------------------------------------ a6/a22 dense layers
 def _linear_pack(weight, transpose):
-    """MFMA fragment stream of a Linear weight (or of a row slice of one, e.g. in_proj_weight[:2C]).  Cached on
-    the owning parameter object, keyed by slice and validated by the tensor version (weights are static in eval)."""
-    owner = weight._base if weight._base is not None else weight
-    cache = owner.__dict__.setdefault("_seg3d_packs", {})
-    key = (weight.storage_offset(), tuple(weight.shape), int(transpose))
-    hit = cache.get(key)
-    if hit is not None and hit[0] == weight._version:
-        return hit[1]
+    """MFMA fragment stream of a Linear weight (or of a row slice of one, e.g. in_proj_weight[:2C]); parameters go
+    through the pack registry (validated by the tensor version, refreshed in one batched launch)."""
+    if _registry_ok(weight) and (weight if weight._base is None else weight._base).is_leaf:
+        return _cached_pack(weight, 1, int(transpose), 0)
     w = _f32c(weight)
     cout, cin = w.shape
     out = torch.empty((_lib.query("seg3d_linear_packed_bytes", cin, cout, int(transpose)),), dtype=torch.uint8,
                       device=w.device)
     _lib.call("seg3d_linear_pack_weight", _ptr(w), cin, cout, int(transpose), _ptr(out), _stream())
-    cache[key] = (weight._version, out)
     return out
 
 

@@ -61,3 +61,36 @@ def test_linear_falls_back_for_unsupported_shapes():
     assert "LinearFn" not in type(y.grad_fn).__name__
     y.sum().backward()
     assert torch.allclose(w.grad, x.sum(0).expand(64, 6), rtol=1e-4, atol=1e-4)
+
+
+def test_batched_pack_refresh_matches_single_packs():
+    """After an in-place update of several parameters the registry repacks all of them in one launch; the streams
+    must equal what the single-weight entry points produce."""
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    lin = [torch.nn.Parameter(torch.randn(co, ci, device=dev)) for co, ci in ((96, 48), (64, 128), (384, 192))]
+    conv = [torch.nn.Parameter(torch.randn(co, 3, 3, 3, ci, device=dev)) for co, ci in ((48, 32), (96, 96))]
+    for rnd in range(2):
+        with torch.no_grad():
+            for p in lin + conv:
+                p.add_(0.5)  # bumps the version: every registered pack is stale
+        got = []
+        for p in lin:
+            got += [ops._linear_pack(p, 0).clone(), ops._linear_pack(p[:32], 1).clone()]
+        for p in conv:
+            got += [ops.pack_weight(p, ops.PACK_FWD).data.clone(), ops.pack_weight(p, ops.PACK_T_FLIP).data.clone()]
+        want = []
+        for p in lin:
+            for w, tr in ((p, 0), (p[:32], 1)):
+                out = torch.empty(_lib.query("seg3d_linear_packed_bytes", w.shape[1], w.shape[0], tr), dtype=torch.uint8, device=dev)
+                _lib.call("seg3d_linear_pack_weight", ops._ptr(w.contiguous()), w.shape[1], w.shape[0], tr, ops._ptr(out), ops._stream())
+                want.append(out)
+        for p in conv:
+            for fl in (4, 4 | 3):
+                out = torch.empty(_lib.query("seg3d_spconv_packed_bytes", p.shape[-1], p.shape[0], fl), dtype=torch.uint8, device=dev)
+                _lib.call("seg3d_spconv_pack_weight", ops._ptr(p), p.shape[-1], p.shape[0], fl, ops._ptr(out), ops._stream())
+                want.append(out)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and torch.equal(a, b), rnd
