@@ -149,6 +149,15 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
 size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int32_t cout);
 int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
                        float* db /* [cout] or NULL */, void* workspace, size_t workspace_bytes, void* stream);
+/* a6  exact-fp32 variant for the per-point MLPs (segformer.py:21-32,58-76), whose split-bf16 forward error would land
+ * directly on the logits: the same contract as seg3d_linear_* on v_mfma_f32_16x16x4_f32;
+ * cin, cout multiples of 16.  Forward: transpose = 0; input gradient: transpose = 1 with cin/cout swapped. */
+size_t seg3d_linear_packed_bytes_f32(int32_t cin, int32_t cout);
+int seg3d_linear_pack_weight_f32(const float* weight, int32_t cin, int32_t cout, int32_t transpose,
+                                 void* w_packed, void* stream);
+int seg3d_linear_fwd_f32(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
+                         int32_t cin, int32_t cout, float* y, void* stream);
+
 /* Batched split-bf16 packing: one launch for every conv / Linear weight whose pack is stale (in training all of
  * them, twice: W for forward, W^T for the input gradient).  `jobs` is a DEVICE array of n_jobs records sorted by
  * first_block; job i covers blocks [first_block_i, first_block_{i+1}) of 256 packed elements each

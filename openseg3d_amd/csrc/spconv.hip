@@ -36,9 +36,9 @@ constexpr int kRowsPerBlock = kWaves * kRowsPerWave;
 // k' = k or 26-k (flip).  Packed as [k'][ci'/16][co'/16][lane 64][j 4]:
 //   lane = ((ci' % 16) / 4) * 16 + (co' % 16),  j = ci' % 4
 // so that one wave-wide float4 load is the B fragment set of four consecutive 16x16x4 MFMAs.
-__global__ __launch_bounds__(256) void pack_weight(const float* __restrict__ w, int cin_src, int cout_src, int transpose,
-                                                   int flip, float* __restrict__ wp) {
-    const int64_t total = (int64_t)27 * cin_src * cout_src;
+__global__ __launch_bounds__(256) void pack_weight(const float* __restrict__ w, int cin_src, int cout_src, int kk,
+                                                   int transpose, int flip, float* __restrict__ wp) {
+    const int64_t total = (int64_t)kk * cin_src * cout_src;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int cin_op = transpose ? cout_src : cin_src;
@@ -52,14 +52,15 @@ __global__ __launch_bounds__(256) void pack_weight(const float* __restrict__ w, 
     const int kp = (int)r;
     const int ci_op = cb * 16 + (lane >> 4) * 4 + j;
     const int co_op = nb * 16 + (lane & 15);
-    const int k = flip ? 26 - kp : kp;
+    const int k = flip ? kk - 1 - kp : kp;
     const int ci = transpose ? co_op : ci_op;
     const int co = transpose ? ci_op : co_op;
-    wp[t] = w[((int64_t)co * 27 + k) * cin_src + ci];
+    wp[t] = w[((int64_t)co * kk + k) * cin_src + ci];
 }
 
 // ------------------------------------------------------------------ fp32 forward / dgrad
-template <int NBT>
+// DENSE: a Linear layer = one offset whose neighbour of row r is row r (exact-fp32 per-point MLPs, a6)
+template <int NBT, bool DENSE>
 __global__ __launch_bounds__(kThreads) void spconv_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const float* __restrict__ wp,
                                                               const float* __restrict__ bias, int cin, int cout,
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(kThreads) void spconv_fwd_kernel(const float* __res
         acc[n] = (f32x4){b, b, b, b};
     }
 
-    for (int k = 0; k < 27; ++k) {
-        const int32_t raw = nbr[(int64_t)k * m_out + my_row_c];
+    for (int k = 0; k < (DENSE ? 1 : 27); ++k) {
+        const int32_t raw = DENSE ? (int32_t)my_row_c : nbr[(int64_t)k * m_out + my_row_c];
         const int32_t idx = row_ok ? raw : -1;
         if (__ballot(idx >= 0) == 0ull) continue;
         const float* xrow = x + (int64_t)(idx >= 0 ? idx : 0) * cin + (lane >> 4) * 4;
@@ -119,7 +120,10 @@ template <int NBT>
 int launch_fwd(const float* x, const int32_t* nbr, int64_t m_out, const float* wp, const float* bias, int cin, int cout,
                float* y, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(m_out, kRowsPerBlock), (unsigned)((cout / 16) / NBT));
-    hipLaunchKernelGGL(spconv_fwd_kernel<NBT>, grid, dim3(kThreads), 0, st, x, nbr, m_out, wp, bias, cin, cout, y);
+    if (nbr == nullptr)
+        hipLaunchKernelGGL((spconv_fwd_kernel<NBT, true>), grid, dim3(kThreads), 0, st, x, nbr, m_out, wp, bias, cin, cout, y);
+    else
+        hipLaunchKernelGGL((spconv_fwd_kernel<NBT, false>), grid, dim3(kThreads), 0, st, x, nbr, m_out, wp, bias, cin, cout, y);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -270,6 +274,18 @@ int launch_wgrad_b(int jb, const float* x, const float* dy, const int32_t* nbr, 
     }
 }
 
+int dispatch_fwd_f32(const float* x, const int32_t* nbr, int64_t m_out, const float* w_packed, const float* bias, int cin,
+                     int cout, float* y, hipStream_t st) {
+    const int nb = cout / 16;
+    if (nb % 12 == 0) return launch_fwd<12>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    if (nb % 8 == 0) return launch_fwd<8>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    if (nb % 6 == 0) return launch_fwd<6>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    if (nb % 4 == 0) return launch_fwd<4>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    if (nb % 3 == 0) return launch_fwd<3>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    if (nb % 2 == 0) return launch_fwd<2>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    return launch_fwd<1>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -287,7 +303,7 @@ int seg3d_spconv_pack_weight(const float* weight, int32_t cin, int32_t cout, int
     hipStream_t st = as_stream(stream);
     if (flags & 4) return spconv_split_pack(weight, cin, cout, 27, flags & 1, (flags >> 1) & 1, w_packed, st);
     const int64_t total = (int64_t)27 * cin * cout;
-    hipLaunchKernelGGL(pack_weight, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout,
+    hipLaunchKernelGGL(pack_weight, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout, 27,
                        flags & 1, (flags >> 1) & 1, static_cast<float*>(w_packed));
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
@@ -300,15 +316,32 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
     if (!x || !nbr || !y) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
     if (pack_flags & 4) return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, cin, cout, y, st);
-    const float* w_packed = static_cast<const float*>(w_packed_v);
-    const int nb = cout / 16;
-    if (nb % 12 == 0) return launch_fwd<12>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
-    if (nb % 8 == 0) return launch_fwd<8>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
-    if (nb % 6 == 0) return launch_fwd<6>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
-    if (nb % 4 == 0) return launch_fwd<4>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
-    if (nb % 3 == 0) return launch_fwd<3>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
-    if (nb % 2 == 0) return launch_fwd<2>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
-    return launch_fwd<1>(x, nbr, m_out, w_packed, bias, cin, cout, y, st);
+    return dispatch_fwd_f32(x, nbr, m_out, static_cast<const float*>(w_packed_v), bias, cin, cout, y, st);
+}
+
+/* a6  exact-fp32 Linear (per-point MLPs): y[m, cout] = x[m, cin] . W^T + bias on v_mfma_f32_16x16x4_f32 -- the
+ * single-offset case of the exact-fp32 gather-GEMM (rocBLAS picks 16x64 / 32x32 macro tiles for these tall-skinny
+ * shapes: 340-470 us per layer at m = 175k). */
+size_t seg3d_linear_packed_bytes_f32(int32_t cin, int32_t cout) {
+    return cin > 0 && cout > 0 ? (size_t)cin * cout * sizeof(float) : 0;
+}
+
+int seg3d_linear_pack_weight_f32(const float* weight, int32_t cin, int32_t cout, int32_t transpose, void* w_packed,
+                                 void* stream) {
+    if (!weight || !w_packed || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15)) return SEG3D_EINVAL;
+    const int64_t total = (int64_t)cin * cout;
+    hipLaunchKernelGGL(pack_weight, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, as_stream(stream), weight, cin,
+                       cout, 1, transpose ? 1 : 0, 0, static_cast<float*>(w_packed));
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+int seg3d_linear_fwd_f32(const float* x, int64_t m, const void* w_packed, const float* bias, int32_t cin, int32_t cout,
+                         float* y, void* stream) {
+    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!x || !y) return SEG3D_EINVAL;
+    return dispatch_fwd_f32(x, nullptr, m, static_cast<const float*>(w_packed), bias, cin, cout, y, as_stream(stream));
 }
 
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout) {

@@ -340,6 +340,26 @@ def _linear_pack(weight, transpose):
     return out
 
 
+def _linear_pack_f32(weight, transpose):
+    """Exact-fp32 MFMA fragment stream of a Linear weight, cached on the parameter while its version is unchanged."""
+    cache = weight.__dict__.setdefault("_seg3d_f32_packs", {})
+    hit = cache.get(int(transpose))
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
+        return hit[1]
+    w = _f32c(weight)
+    cout, cin = w.shape
+    out = torch.empty((_lib.query("seg3d_linear_packed_bytes_f32", cin, cout),), dtype=torch.uint8, device=w.device)
+    _lib.call("seg3d_linear_pack_weight_f32", _ptr(w), cin, cout, int(transpose), _ptr(out), _stream())
+    cache[int(transpose)] = ((weight._version, weight.data_ptr()), out)
+    return out
+
+
+def _linear_apply_f32(x, packed, bias, cin, cout):
+    y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
+    _lib.call("seg3d_linear_fwd_f32", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), cin, cout, _ptr(y), _stream())
+    return y
+
+
 def _linear_apply(x, packed, bias, cin, cout):
     y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
     _lib.call("seg3d_linear_fwd", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), cin, cout, _ptr(y), _stream())
@@ -356,7 +376,9 @@ class _LinearFn(torch.autograd.Function):
         cout, cin = weight.shape
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.exact = bias is not None, exact
-        if exact:  # fp32 GEMM (rocBLAS/hipBLASLt); only the weight gradient uses the split kernel
+        if exact:  # exact-fp32 MFMA kernel (rocBLAS for odd shapes); only the weight gradient uses the split kernel
+            if cin % 16 == 0 and cout % 16 == 0:
+                return _linear_apply_f32(x, _linear_pack_f32(weight, 0), None if bias is None else _f32c(bias), cin, cout)
             return torch.nn.functional.linear(x, weight, bias)
         return _linear_apply(x, _linear_pack(weight, 0), None if bias is None else _f32c(bias), cin, cout)
 
@@ -369,6 +391,8 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if not ctx.exact and cout % 8 == 0 and cin % 16 == 0:
                 dx = _linear_apply(dy, _linear_pack(weight, 1), None, cout, cin)
+            elif ctx.exact and cout % 16 == 0 and cin % 16 == 0:
+                dx = _linear_apply_f32(dy, _linear_pack_f32(weight, 1), None, cout, cin)
             else:
                 dx = dy @ weight
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -385,15 +409,59 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _LinearOddShapeFn(torch.autograd.Function):
+    """Linear layers whose shape does not fit the MFMA tiles (6 -> 64 input layer, -> 22 classifiers): forward and
+    input gradient stay on rocBLAS, the weight gradient -- a 64 x 6 or 22 x 64 output reduced over 1e5 rows, for which
+    rocBLAS takes 340-470 us -- runs on the split-bf16 tall-skinny kernel over zero-padded (multiple-of-4) columns."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _f32c(x)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32c(dy)
+        cout, cin = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ weight
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            pi, po = (-cin) % 4, (-cout) % 4
+            xp = torch.nn.functional.pad(x, (0, pi)) if pi else x
+            dyp = torch.nn.functional.pad(dy, (0, po)) if po else dy
+            dwp = torch.empty((cout + po, cin + pi), dtype=torch.float32, device=dy.device)
+            dbp = torch.empty((cout + po,), dtype=torch.float32, device=dy.device) if want_db else None
+            ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin + pi, cout + po)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
+            _lib.call("seg3d_linear_wgrad", _ptr(xp), _ptr(dyp), x.shape[0], cin + pi, cout + po, _ptr(dwp), _ptr(dbp),
+                      _ptr(ws), ws_bytes, _stream())
+            dw = dwp[:cout, :cin]
+            if want_db:
+                db = dbp[:cout]
+        elif want_db:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
 def linear(x, weight, bias=None, exact=False):
     """F.linear for [rows, C] activations.  Layers whose shape fits the MFMA tiles (cin % 8 == 0,
     cout % 16 == 0) run in libseg3d_hip.so in split-bf16 arithmetic; the rest (6 -> 64 input layer, -> 22
-    classifiers) stay on rocBLAS.  ``exact=True`` keeps forward and input gradient on the fp32 GEMM and only
-    takes the weight gradient from the split kernel: used by the per-point MLPs, whose ~2^-16 relative forward
+    classifiers) stay on rocBLAS.  ``exact=True`` keeps forward and input gradient in exact fp32 (v_mfma_f32_16x16x4_f32
+    kernel, rocBLAS for shapes it does not take) and only takes the weight gradient from the split kernel: used by the per-point MLPs, whose ~2^-16 relative forward
     error would land directly on the O(25) logits (measured 1e-3 absolute) instead of being washed out by the
     LayerNorms of the voxel path."""
     fits = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 16 == 0
             and weight.shape[1] % 8 == 0 and CONV_PRECISION == "bf16x3")
+    if exact and fits and weight.shape[1] % 16 == 0:
+        return _LinearFn.apply(x, weight, bias, True)  # exact-fp32 MFMA forward / input gradient, split wgrad
+    if not fits and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and CONV_PRECISION == "bf16x3" \
+            and torch.is_grad_enabled() and weight.requires_grad and x.shape[0] >= 4096:
+        return _LinearOddShapeFn.apply(x, weight, bias)
     if not fits or (exact and not (torch.is_grad_enabled() and weight.requires_grad)):
         return torch.nn.functional.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias, exact)

@@ -166,8 +166,8 @@ class PointTransformer(nn.Module):
         self.up3 = UpBlock(192, 96, norm_fn, act_fn, "inverseconv", 3)
         self.up2 = UpBlock(96, 48, norm_fn, act_fn, "inverseconv", 2)
         self.up1 = UpBlock(48, output_channels, norm_fn, act_fn, "subm", 1)
-        self.aux_voxel_classifier = nn.Sequential(nn.Linear(384, num_classes, bias=False))
-        self.voxel_classifier = nn.Sequential(nn.Linear(output_channels, num_classes, bias=False))
+        self.aux_voxel_classifier = nn.Sequential(RowLinear(384, num_classes, bias=False))
+        self.voxel_classifier = nn.Sequential(RowLinear(output_channels, num_classes, bias=False))
 
     def forward(self, batch_dict):
         x = spconv.SparseConvTensor(features=batch_dict["voxel_features"], indices=batch_dict["voxel_coords"].int(),
@@ -291,7 +291,7 @@ class Segformer(nn.Module):
         self.se = FlattenSELayer(self.fusion_feature_channel)
         self.classifier = FusedMLP(RowLinear(self.fusion_feature_channel, 64, bias=False), nn.BatchNorm1d(64),
                                    nn.ReLU(True), nn.Dropout(0.3),
-                                   nn.Linear(64, dataset.num_classes, bias=False))
+                                   RowLinear(64, dataset.num_classes, bias=False))
         self.weight_initialization()
 
     def weight_initialization(self):

@@ -56,11 +56,34 @@ def test_linear_falls_back_for_unsupported_shapes():
     from openseg3d_amd import ops
     dev = torch.device("cuda:0")
     x = torch.randn(100, 6, device=dev)
-    w = torch.randn(64, 6, device=dev, requires_grad=True)  # cin % 4 != 0 -> rocBLAS path
+    w = torch.randn(64, 6, device=dev, requires_grad=True)  # cin % 4 != 0, few rows -> rocBLAS path
     y = ops.linear(x, w)
     assert "LinearFn" not in type(y.grad_fn).__name__
     y.sum().backward()
     assert torch.allclose(w.grad, x.sum(0).expand(64, 6), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("m,cin,cout,bias", [(20000, 6, 64, False), (50001, 64, 22, False), (8192, 10, 22, True)])
+def test_odd_shape_linear_weight_gradient(m, cin, cout, bias):
+    """6 -> 64 and -> 22 layers: rocBLAS forward / dX, padded split-bf16 weight gradient."""
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(cin * 100 + cout)
+    x, w, g = torch.randn(m, cin), torch.randn(cout, cin) / cin ** 0.5, torch.randn(m, cout)
+    b = torch.randn(cout) if bias else None
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if bias else None
+    torch.nn.functional.linear(xr, wr, br).backward(g.double())
+    xg, wg = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+    bg = b.to(dev).requires_grad_() if bias else None
+    y = ops.linear(xg, wg, bg, exact=True)
+    assert "OddShape" in type(y.grad_fn).__name__
+    y.backward(g.to(dev))
+    scale = max(1.0, float(wr.grad.abs().max()))
+    assert float((wg.grad.cpu().double() - wr.grad).abs().max()) < 1e-4 * scale
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 1e-4
+    if bias:
+        assert float((bg.grad.cpu().double() - br.grad).abs().max()) < 1e-3 * max(1.0, float(br.grad.abs().max()))
 
 
 def test_batched_pack_refresh_matches_single_packs():

@@ -84,6 +84,18 @@ def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
         bn.running_var.copy_(0.5 + torch.rand(c))
     ref = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
     ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    if relu:
+        # keep every pre-activation away from the ReLU kink: the GPU sums the batch statistics in a run-dependent
+        # order, so an element within rounding of zero may take the other branch and move dx / dgamma by O(1)
+        for _ in range(4):
+            with torch.no_grad():
+                pre = torch.nn.functional.batch_norm(x.double(), None, None, ref.weight, ref.bias, True, 0.0, 1e-3)
+                if with_res:
+                    pre = pre + r.double()
+                near = pre.abs() < 2e-3
+                if not bool(near.any()):
+                    break
+                x[near] += 0.05
 
     pre_ref = []
 
@@ -104,13 +116,11 @@ def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
     assert "BatchNormAct" in type(y.grad_fn).__name__
     y.backward(g.to(dev))
     assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 5e-5
-    # an element whose pre-activation is within rounding of zero may take the other side of the ReLU on the GPU
-    # (the batch statistics are summed in a run-dependent order): its own gradient is not comparable
-    sure = (pre_ref[0].abs() > 1e-4) if relu else torch.ones_like(yr, dtype=torch.bool)
-    assert float(sure.double().mean()) > 0.999
-    assert float(((xg.grad.cpu().double() - xr.grad).abs() * sure).max()) < 5e-5
+    if relu:
+        assert float(pre_ref[0].abs().min()) > 1e-3
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 5e-5
     if with_res:
-        assert float(((rg.grad.cpu().double() - rr.grad).abs() * sure).max()) < 1e-6
+        assert float((rg.grad.cpu().double() - rr.grad).abs().max()) < 1e-6
     for got, want in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
         assert float((got.cpu().double() - want).abs().max()) < 1e-3 * max(1.0, float(want.abs().max()))
     assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) < 1e-5
