@@ -160,8 +160,8 @@ int seg3d_linear_fwd_f32(const float* x, int64_t m, const void* w_packed, const 
 
 /* Batched split-bf16 packing: one launch for every conv / Linear weight whose pack is stale (in training all of
  * them, twice: W for forward, W^T for the input gradient).  `jobs` is a DEVICE array of n_jobs records sorted by
- * first_block; job i covers blocks [first_block_i, first_block_{i+1}) of 256 packed elements each
- * (ceil(packed_bytes / 2 / 256) blocks); dst as for seg3d_spconv_pack_weight (flags bit2 set) /
+ * first_block; job i covers blocks [first_block_i, first_block_{i+1}) of 256 work items each, one item = 16 packed
+ * elements (ceil(packed_bytes / 32 / 256) blocks); dst as for seg3d_spconv_pack_weight (flags bit2 set) /
  * seg3d_linear_pack_weight.  kk = 27 (conv, weight [Cout,27,Cin]) or 1 (Linear, weight [Cout,Cin]). */
 typedef struct {
   const float* src;     /* weight in the reference layout */

@@ -48,33 +48,40 @@ __device__ __forceinline__ void split8(const f32x4& p, const f32x4& q, bf16x8* h
 }
 
 // packed stream: [k'][cin_op/32 (padded)][cout_op/16][2: hi,lo][64 lanes][8 bf16];
-// lane = (ci%32)/8 * 16 + co%16, element j = ci%8
-__global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict__ w, int cin_src, int cout_src, int kk,
-                                                         int transpose, int flip, __bf16* __restrict__ wp) {
+// lane = (ci%32)/8 * 16 + co%16, element j = ci%8.  One thread produces one lane's 8 elements of both halves
+// (two 16-B stores); item index = ((k' * cb_n + cb) * nb_n + nb) * 64 + lane.
+__device__ __forceinline__ void pack_item(const float* __restrict__ w, int cin_src, int cout_src, int kk, int transpose,
+                                          int flip, int64_t item, __bf16* __restrict__ wp) {
     const int cin_op = transpose ? cout_src : cin_src;
     const int cout_op = transpose ? cin_src : cout_src;
     const int cb_n = (cin_op + 31) / 32, nb_n = cout_op / 16;
-    const int64_t total = (int64_t)kk * cb_n * nb_n * 1024;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    int64_t r = t;
-    const int j = (int)(r & 7); r >>= 3;
+    int64_t r = item;
     const int lane = (int)(r & 63); r >>= 6;
-    const int h = (int)(r & 1); r >>= 1;
     const int nb = (int)(r % nb_n); r /= nb_n;
     const int cb = (int)(r % cb_n); r /= cb_n;
     const int kp = (int)r;
-    const int ci_op = cb * 32 + (lane >> 4) * 8 + j;
+    const int k = flip ? kk - 1 - kp : kp;
+    const int ci0 = cb * 32 + (lane >> 4) * 8;
     const int co_op = nb * 16 + (lane & 15);
-    float v = 0.f;
-    if (ci_op < cin_op) {
-        const int k = flip ? kk - 1 - kp : kp;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci_op = ci0 + j;
         const int ci = transpose ? co_op : ci_op;
         const int co = transpose ? ci_op : co_op;
-        v = w[((int64_t)co * kk + k) * cin_src + ci];
+        v[j] = ci_op < cin_op ? w[((int64_t)co * kk + k) * cin_src + ci] : 0.f;
     }
-    const __bf16 hi = (__bf16)v;
-    wp[t] = h ? (__bf16)(v - (float)hi) : hi;
+    bf16x8 hi, lo;
+    split8((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4], v[5], v[6], v[7]}, &hi, &lo);
+    const int64_t base = ((item >> 6) * 2) * 512 + (int64_t)lane * 8;  // (k', cb, nb) block of 2 x 64 x 8 elements
+    *reinterpret_cast<bf16x8*>(wp + base) = hi;
+    *reinterpret_cast<bf16x8*>(wp + base + 512) = lo;
+}
+
+__global__ __launch_bounds__(256) void pack_weight_split(const float* __restrict__ w, int cin_src, int cout_src, int kk,
+                                                         int transpose, int flip, int64_t items, __bf16* __restrict__ wp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < items) pack_item(w, cin_src, cout_src, kk, transpose, flip, t, wp);
 }
 
 // One launch for many weights (all conv and Linear packs of a training step: the weights change every optimizer
@@ -97,28 +104,9 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
     const PackJob jb = jobs[lo];
     const int cin_op = jb.transpose ? jb.cout_src : jb.cin_src;
     const int cout_op = jb.transpose ? jb.cin_src : jb.cout_src;
-    const int cb_n = (cin_op + 31) / 32, nb_n = cout_op / 16;
-    const int64_t total = (int64_t)jb.kk * cb_n * nb_n * 1024;
+    const int64_t items = (int64_t)jb.kk * ((cin_op + 31) / 32) * (cout_op / 16) * 64;
     const int64_t t = ((int64_t)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
-    if (t >= total) return;
-    int64_t r = t;
-    const int j = (int)(r & 7); r >>= 3;
-    const int lane = (int)(r & 63); r >>= 6;
-    const int h = (int)(r & 1); r >>= 1;
-    const int nb = (int)(r % nb_n); r /= nb_n;
-    const int cb = (int)(r % cb_n); r /= cb_n;
-    const int kp = (int)r;
-    const int ci_op = cb * 32 + (lane >> 4) * 8 + j;
-    const int co_op = nb * 16 + (lane & 15);
-    float v = 0.f;
-    if (ci_op < cin_op) {
-        const int k = jb.flip ? jb.kk - 1 - kp : kp;
-        const int ci = jb.transpose ? co_op : ci_op;
-        const int co = jb.transpose ? ci_op : co_op;
-        v = jb.src[((int64_t)co * jb.kk + k) * jb.cin_src + ci];
-    }
-    const __bf16 hi16 = (__bf16)v;
-    jb.dst[t] = h ? (__bf16)(v - (float)hi16) : hi16;
+    if (t < items) pack_item(jb.src, jb.cin_src, jb.cout_src, jb.kk, jb.transpose, jb.flip, t, jb.dst);
 }
 
 template <int NBT, int RB, bool DENSE>
@@ -340,9 +328,9 @@ size_t spconv_split_packed_bytes(int cin_op, int cout_op, int kk) {
 int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transpose, int flip, void* w_packed,
                       hipStream_t st) {
     const int cin_op = transpose ? cout : cin, cout_op = transpose ? cin : cout;
-    const int64_t total = (int64_t)kk * ((cin_op + 31) / 32) * (cout_op / 16) * 1024;
-    hipLaunchKernelGGL(pack_weight_split, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, weight, cin, cout, kk,
-                       transpose, flip, reinterpret_cast<__bf16*>(w_packed));
+    const int64_t items = (int64_t)kk * ((cin_op + 31) / 32) * (cout_op / 16) * 64;
+    hipLaunchKernelGGL(pack_weight_split, dim3((unsigned)ceil_div64(items, 256)), dim3(256), 0, st, weight, cin, cout, kk,
+                       transpose, flip, items, reinterpret_cast<__bf16*>(w_packed));
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

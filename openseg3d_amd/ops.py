@@ -210,7 +210,7 @@ def _cached_pack(weight, kk, transpose, flip):
         nbytes = (_lib.query("seg3d_spconv_packed_bytes", cin, cout, 4 | job.transpose) if kk == 27
                   else _lib.query("seg3d_linear_packed_bytes", cin, cout, job.transpose))
         job.out = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
-        job.blocks = (nbytes // 2 + 255) // 256
+        job.blocks = (nbytes // 32 + 255) // 256  # one work item = 16 packed bf16 (a lane's hi and lo fragments)
         job.version = -1
         _PACK_JOBS[key] = job
         _PACK_DESC.clear()
