@@ -82,25 +82,25 @@ def conv_roofline(model, batch, dev):
         return y
 
     attn_records = []
-    orig_attn = ops.window_attention
+    orig_attn = ops.window_attention_packed
 
-    def timed_attn(q, k, v, tau, tau_min, heads, wi):  # noqa: E306
+    def timed_attn(qk, v, tau, tau_min, heads, wi):  # noqa: E306
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        o = orig_attn(q, k, v, tau, tau_min, heads, wi)
+        o = orig_attn(qk, v, tau, tau_min, heads, wi)
         e1.record()
         attn_records.append((wi, v.shape[1], e0, e1))
         return o
 
     ops._conv_apply = timed
-    ops.window_attention = timed_attn
+    ops.window_attention_packed = timed_attn
     try:
         with torch.no_grad():
             model(dict(batch))
         torch.cuda.synchronize()
     finally:
         ops._conv_apply = orig
-        ops.window_attention = orig_attn
+        ops.window_attention_packed = orig_attn
     # window attention (prepare + core kernels of one layer): algorithmic FLOPs 4*C*sum_w n_w^2
     sq_cache, a_flop, a_ms = {}, 0.0, 0.0
     for wi, c, e0, e1 in attn_records:

@@ -662,6 +662,111 @@ class _WindowAttnFn(torch.autograd.Function):
         return dq, dk, dv, dtau.reshape(tau.shape), None, None, None
 
 
+class _WindowAttnPackedFn(torch.autograd.Function):
+    """Same kernels on the packed in-projection output qk [m, 2C] (q | k): the gradient comes back as one [m, 2C]
+    tensor written in place by the backward kernels (row stride 2C), so autograd never materialises the two
+    zero-filled slice gradients of q = qk[:, :C], k = qk[:, C:] and their sum."""
+
+    @staticmethod
+    def forward(ctx, qk, v, tau, tau_min, heads, wi):
+        m, c = v.shape
+        dh = c // heads
+        dev = v.device
+        out = torch.empty((m, c), dtype=torch.float32, device=dev)
+        lse = torch.empty((m, heads), dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, dh), dev)
+        kp = ctypes.c_void_p(qk.data_ptr() + 4 * c)
+        _lib.call("seg3d_window_attn_fwd", _ptr(qk), kp, _ptr(v), 2 * c, 2 * c, c,
+                  _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0), _ptr(wi.tile_item),
+                  int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m, int(wi.n_windows), heads, dh,
+                  _ptr(tau.reshape(-1)), float(tau_min), _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+        ctx.save_for_backward(qk, v, tau, out, lse)
+        ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qk, v, tau, out, lse = ctx.saved_tensors
+        wi, heads = ctx.wi, ctx.heads
+        m, c = v.shape
+        dev = v.device
+        dout = _f32c(dout)
+        dqk = torch.empty((m, 2 * c), dtype=torch.float32, device=dev)
+        dv = torch.empty((m, c), dtype=torch.float32, device=dev)
+        dtau = torch.zeros((1,), dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, c // heads), dev)
+        kp = ctypes.c_void_p(qk.data_ptr() + 4 * c)
+        dkp = ctypes.c_void_p(dqk.data_ptr() + 4 * c)
+        _lib.call("seg3d_window_attn_bwd", _ptr(qk), kp, _ptr(v), 2 * c, 2 * c, c,
+                  _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count),
+                  _ptr(wi.win_tile0), _ptr(wi.tile_item), int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m,
+                  int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), _ptr(dqk), dkp,
+                  _ptr(dv), 2 * c, 2 * c, c, _ptr(dtau), _ptr(ws), ws.numel(), _stream())
+        return dqk, dv, dtau.reshape(tau.shape), None, None, None
+
+
+def window_attention_packed(qk, v, tau, tau_min, heads, wi):
+    """qk: contiguous float32 [m, 2C] (q | k), v: contiguous float32 [m, C]."""
+    _need_gpu(qk, v, tau)
+    if qk.dtype != torch.float32 or v.dtype != torch.float32 or not qk.is_contiguous() or not v.is_contiguous() \
+            or qk.shape[1] != 2 * v.shape[1]:
+        raise _lib.Seg3dError("qk must be contiguous float32 [m, 2C] and v contiguous float32 [m, C]")
+    return _WindowAttnPackedFn.apply(qk, v, tau, tau_min, heads, wi)
+
+
+class _AttnInProjFn(torch.autograd.Function):
+    """In-projection of the cosine attention (cosine_msa.py:58-63): qk = (x + pos) W_qk^T + b_qk, v = x W_v^T + b_v with
+    the packed parameters in_proj_weight [3C, C] / in_proj_bias [3C].  One backward produces dx (both paths summed),
+    dpos and the full dW / db (the two weight-gradient calls write the two row blocks in place): autograd sees no
+    parameter slices, hence no zero-filled slice gradients and no extra adds."""
+
+    @staticmethod
+    def forward(ctx, x, pos, w_in, b_in):
+        x = _f32c(x)
+        c = x.shape[1]
+        xp = x + pos
+        qk = _linear_apply(xp, _linear_pack(w_in[: 2 * c], 0), b_in[: 2 * c], c, 2 * c)
+        v = _linear_apply(x, _linear_pack(w_in[2 * c:], 0), b_in[2 * c:], c, c)
+        ctx.save_for_backward(x, xp, w_in)
+        return qk, v
+
+    @staticmethod
+    def backward(ctx, dqk, dv):
+        x, xp, w_in = ctx.saved_tensors
+        c = x.shape[1]
+        m = x.shape[0]
+        dqk, dv = _f32c(dqk), _f32c(dv)
+        dx = dpos = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            d_xp = _linear_apply(dqk, _linear_pack(w_in[: 2 * c], 1), None, 2 * c, c)
+            if ctx.needs_input_grad[1]:
+                dpos = d_xp
+            if ctx.needs_input_grad[0]:
+                dx = _linear_apply(dv, _linear_pack(w_in[2 * c:], 1), None, c, c)
+                dx += d_xp
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty((3 * c, c), dtype=torch.float32, device=x.device)
+            db = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
+            for src, dy, r0, rows in ((xp, dqk, 0, 2 * c), (x, dv, 2 * c, c)):
+                ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, c, rows)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+                _lib.call("seg3d_linear_wgrad", _ptr(src), _ptr(dy), m, c, rows, ctypes.c_void_p(dw.data_ptr() + 4 * r0 * c),
+                          ctypes.c_void_p(db.data_ptr() + 4 * r0), _ptr(ws), ws_bytes, _stream())
+        return dx, dpos, dw, (db if ctx.needs_input_grad[3] else None)
+
+
+def attn_in_proj(x, pos, w_in, b_in):
+    """(qk [m, 2C], v [m, C]) of the packed cosine-attention in-projection; falls back to three F.linear-style calls
+    when the shapes do not fit the MFMA tiles."""
+    c = x.shape[1]
+    fits = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and c % 16 == 0 and CONV_PRECISION == "bf16x3"
+            and w_in.is_contiguous() and b_in is not None)
+    if not fits:
+        return linear(x + pos, w_in[: 2 * c], None if b_in is None else b_in[: 2 * c]), \
+            linear(x, w_in[2 * c:], None if b_in is None else b_in[2 * c:])
+    return _AttnInProjFn.apply(x, pos, w_in, b_in)
+
+
 def window_attention(q, k, v, tau, tau_min, heads, wi):
     """q, k, v: float32 [m, C] row-strided views (last dim contiguous) of the in-projection output."""
     _need_gpu(q, k, v, tau)

@@ -119,10 +119,8 @@ class CosineMultiheadAttention(nn.Module):
 
     def forward(self, x, pos, wi):
         """x [M, C] flat voxel features, pos [M, C]; q = k = (x + pos) W_qk, v = x W_v (cosine_msa.py:58-63)."""
-        c = self.embed_dim
-        qk = ops.linear(x + pos, self.in_proj_weight[: 2 * c], self.in_proj_bias[: 2 * c])
-        v = ops.linear(x, self.in_proj_weight[2 * c:], self.in_proj_bias[2 * c:])
-        o = ops.window_attention(qk[:, :c], qk[:, c:], v, self.tau, self.tau_min, self.num_heads, wi)
+        qk, v = ops.attn_in_proj(x, pos, self.in_proj_weight, self.in_proj_bias)
+        o = ops.window_attention_packed(qk, v, self.tau, self.tau_min, self.num_heads, wi)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
