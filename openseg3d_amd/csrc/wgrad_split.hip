@@ -18,6 +18,8 @@
 // order -- bit-reproducible, no memset of dw.
 // Block order: id -> (xcd = id % 8, j = id / 8), unit = 8 * (j / tiles) + xcd = (chunk, offset), block = j % tiles:
 // the workgroups that read the same gathered rows are dispatched back to back on one XCD and share its L2.
+#include <cstdlib>
+
 #include "attn_common.hpp"
 
 int wgrad_chunk_reduce(const float* part, int chunks, int64_t n, int64_t nw, float* dw, float* db, hipStream_t st);
@@ -194,6 +196,160 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide channels (C >= 128): the 64 x 64 kernel above re-reads its gathered rows once per block and is bound by that
+// L2 -> L1 stream.  Here a workgroup of 2 x 2 waves owns a 128 x 128 block of dw[:, k, :]: per 32-pair step wave w
+// loads ONE 64-channel slab (waves 0,1: dy channels co0.., co0+64..; waves 2,3: x channels ci0.., ci0+64..) with the
+// same 8-pairs x 4-channels-per-lane pattern, converts it to bf16 hi/lo records and writes them to a double-buffered
+// LDS image [slab][hi|lo][row group][64 records] (record (c%4)*16 + c/4 of row group g = channel c, pairs 8g..8g+7,
+// conflict-free 16-B accesses both ways); after one barrier wave (wa, wb) reads slab wa as A and slab 2+wb as B and
+// issues its 48 MFMAs.  Half the operand traffic and half the conversions per MFMA.  The pair list is compacted once
+// per workgroup: each wave ballots 64 of 256 rows, wave totals are exchanged through LDS.  The slab loads of step
+// s+1 are issued before the MFMAs of step s.
+constexpr int kRing2 = 512;  // pairs: at most 31 left over + 256 new
+
+__global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                         const int32_t* __restrict__ nbr, int64_t m_rows,
+                                                                         int cin, int cout, int rows_per_chunk, int nbi,
+                                                                         int tiles, int units, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) uint4 img[2][4][2][4][64];  // [buffer][slab][hi|lo][row group][record] 64 KiB
+    __shared__ int2 ring[kRing2];
+    __shared__ int wave_cnt[2][kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cq = lane & 15, rg = lane >> 4;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int unit = (j / tiles) * 8 + xcd, tile = j % tiles;
+    if (unit >= units) return;  // padding of the XCD-aligned grid (whole workgroup)
+    const int chunk = unit / 27, k = unit % 27;
+    const int bi = tile % nbi, bo = tile / nbi;
+    const int ci0 = bi * 128, co0 = bo * 128;
+    const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
+    const int64_t r_end = r_begin + rows_per_chunk < m_rows ? r_begin + rows_per_chunk : m_rows;
+    const int32_t* nk = nbr + (int64_t)k * m_rows;
+    // this wave's slab: waves 0,1 stage dy (rows = output rows), waves 2,3 stage x (rows = gathered input rows)
+    const bool stage_dy = wave < 2;
+    const int ld = stage_dy ? cout : cin;
+    const int ch = (stage_dy ? co0 : ci0) + 64 * (wave & 1) + 4 * cq;
+    const float* src = (stage_dy ? dy : x) + (ch < ld ? ch : 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- pair compaction, 256 rows per round (64 per wave); cursors are identical in every wave
+    int head = 0, tail = 0, round = 0;
+    int64_t g_row = r_begin;
+    auto scan_round = [&]() {
+        const int64_t row = g_row + 64 * wave + lane;
+        const int32_t idx = row < r_end ? nk[row] : -1;
+        const unsigned long long mask = __ballot(idx >= 0);
+        const int mine = __popcll(mask);
+        int* cnt = wave_cnt[round & 1];
+        if (lane == 0) cnt[wave] = mine;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const int c = cnt[w];
+            before += w < wave ? c : 0;
+            total += c;
+        }
+        if (idx >= 0) {
+            const int p = tail + before + __popcll(mask & ((1ull << lane) - 1ull));
+            ring[p & (kRing2 - 1)] = make_int2(idx, (int)row);
+        }
+        tail += total;
+        g_row += 64 * kWaves;
+        ++round;
+    };
+    auto refill = [&]() {  // every wave takes the same branches
+        while (tail - head < 32 && g_row < r_end) scan_round();
+        __syncthreads();  // ring writes visible
+    };
+
+    f32x4 raw[8];
+    auto load_slab = [&](int h0, int valid) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = 8 * rg + i;
+            const int2 p = ring[(h0 + (e < valid ? e : 0)) & (kRing2 - 1)];
+            raw[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)(stage_dy ? p.y : p.x) * ld);
+        }
+        if (valid < 32) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * rg + i >= valid) raw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = raw[i][jj];
+            bf16x8 hi, lo;
+            split_frag(v, &hi, &lo);
+            img[buf][wave][0][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, hi);
+            img[buf][wave][1][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, lo);
+        }
+    };
+    auto multiply = [&](int buf) {
+        bf16x8 b_hi[4], b_lo[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            b_hi[b] = __builtin_bit_cast(bf16x8, img[buf][2 + wb][0][rg][b * 16 + cq]);
+            b_lo[b] = __builtin_bit_cast(bf16x8, img[buf][2 + wb][1][rg][b * 16 + cq]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bf16x8 a_hi = __builtin_bit_cast(bf16x8, img[buf][wa][0][rg][a * 16 + cq]);
+            const bf16x8 a_lo = __builtin_bit_cast(bf16x8, img[buf][wa][1][rg][a * 16 + cq]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+        }
+    };
+
+    refill();
+    int valid = tail - head < 32 ? tail - head : 32;
+    int buf = 0;
+    if (valid > 0) {
+        load_slab(head, valid);
+        stash(0);
+    }
+    while (valid > 0) {
+        head += valid;
+        refill();  // also the barrier that publishes image `buf`
+        const int next = tail - head < 32 ? tail - head : 32;
+        if (next > 0) load_slab(head, next);
+        multiply(buf);
+        if (next > 0) stash(buf ^ 1);
+        buf ^= 1;
+        valid = next;
+    }
+    __syncthreads();  // all reads of the images done: reuse them as the store staging area
+
+    // ---- store: acc[a][b][r] = dw[co = 4*(4g + r) + a][ci = 4*c16 + b] of this wave's 64 x 64 sub-block
+    float* st = reinterpret_cast<float*>(&img[0][0][0][0][0]) + wave * 4096;  // 16 KiB per wave
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(&st[(4 * (4 * rg + r) + a) * 64 + 4 * cq]) =
+                (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+    __builtin_amdgcn_wave_barrier();
+    float* pw = part + (int64_t)chunk * ((int64_t)cout * 27 * cin);
+    for (int e = lane; e < 64 * 16; e += 64) {
+        const int row = e >> 4, q = e & 15;
+        const int co = co0 + 64 * wa + row, ci = ci0 + 64 * wb + 4 * q;
+        if (co < cout && ci < cin)
+            *reinterpret_cast<f32x4*>(pw + ((int64_t)co * 27 + k) * cin + ci) =
+                *reinterpret_cast<const f32x4*>(&st[row * 64 + 4 * q]);
+    }
+}
+
 }  // namespace
 
 // used by seg3d_spconv_wgrad (spconv.hip)
@@ -207,10 +363,21 @@ int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int6
     if (workspace_bytes < wgrad_split_sparse_workspace_bytes(m_out, cin, cout) || !workspace) return SEG3D_EINVAL;
     const Plan p = plan(m_out, cin, cout);
     float* part = static_cast<float*>(workspace);
-    const int tiles = p.nbo * p.nbi, units = p.chunks * 27;
-    const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
-    hipLaunchKernelGGL(wgrad_sparse_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout, (int)p.rows,
-                       p.nbi, tiles, units, part);
+    const int units = p.chunks * 27;
+    static const bool narrow_only = getenv("SEG3D_WGRAD_NARROW") != nullptr;  // A/B switch for profiling
+    // 128-wide blocks only where they add no padding (C = 256, 384, 768; not 192 = 1.5 blocks)
+    const bool fits128 = ((cin + 127) / 128) * 2 == (cin + 63) / 64 && ((cout + 127) / 128) * 2 == (cout + 63) / 64;
+    if (fits128 && !narrow_only) {
+        const int nbo = (cout + 127) / 128, nbi = (cin + 127) / 128, tiles = nbo * nbi;
+        const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
+        hipLaunchKernelGGL(wgrad_sparse_wide_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
+                           (int)p.rows, nbi, tiles, units, part);
+    } else {
+        const int tiles = p.nbo * p.nbi;
+        const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
+        hipLaunchKernelGGL(wgrad_sparse_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
+                           (int)p.rows, p.nbi, tiles, units, part);
+    }
     SEG3D_CHECK_LAUNCH();
     const int64_t n = (int64_t)27 * cin * cout;
     return wgrad_chunk_reduce(part, p.chunks, n, n, dw, nullptr, st);
