@@ -260,7 +260,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
  *     y = res + rowscale_row * ((x - mean_row) * rstd_row * gamma + beta)
  * res may be NULL; rowscale [m] (the per-row DropPath factor, seg3d/models/layers/drop.py:6-19) may be NULL = 1;
  * mean/rstd [m] are kept for the backward pass.
- * backward: dx, and dgamma/dbeta [c] (zeroed inside, accumulated with one float atomic per channel per block);
+ * backward: dx, and dgamma/dbeta [c] (per-block partial sums in the workspace, summed in a fixed order: deterministic);
  * the residual's gradient is dy itself.
  * BatchNorm1d (+ residual) (+ ReLU) of the conv blocks / point MLPs (spconv_utils.py:13-32,
  * pointtransformer.py:47-66, segformer.py:21-76):
@@ -276,9 +276,10 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
 int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
                         const float* rowscale, float eps, int64_t m, int32_t c, float* y, float* mean,
                         float* rstd, void* stream);
+size_t seg3d_layernorm_bwd_workspace_bytes(int64_t m, int32_t c);
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* rowscale, int64_t m, int32_t c, float* dx,
-                        float* dgamma, float* dbeta, void* stream);
+                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* stream);
 int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const float* gamma, const float* beta,
                           float momentum, float* running_mean, float* running_var, float* stats, void* stream);

@@ -14,6 +14,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;
+constexpr int kLnBwdMaxBlocks = 1024;
 
 // A wave covers R = 64 / P rows; a row is spread over P lanes (P = pow2 >= quads / ITEMS), every lane owning
 // ITEMS float4 "quads" of its row: quad q = lane_in_row + i * P.
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ rowscale,
                                                           int64_t m, int c, RowMap rm, float* __restrict__ dx,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          float* __restrict__ part /*[gridDim.x][2][c]*/) {
     extern __shared__ float red[];  // [2][c] block partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows_per_wave = 64 / rm.p;
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
             }
         }
     }
-    // block partials: LDS float atomics (few per thread), then one global atomic per channel per block
+    // block partials: LDS float atomics (few per thread), then one plain store per channel per block; ln_bwd_reduce
+    // sums the blocks in a fixed order (no contended global atomics, no memset, deterministic)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int q = lq + i * rm.p;
@@ -168,9 +170,26 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < c; i += kThreads) {
-        atomicAdd(&dgamma[i], red[i]);
-        atomicAdd(&dbeta[i], red[c + i]);
+    for (int i = threadIdx.x; i < 2 * c; i += kThreads) part[(int64_t)blockIdx.x * 2 * c + i] = red[i];
+}
+
+// dgamma[i] = sum_b part[b][i], dbeta[i] = sum_b part[b][c + i]; 32 block lanes per column, combined in lane order
+__global__ __launch_bounds__(1024) void ln_bwd_reduce(const float* __restrict__ part, int nblocks, int c,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[32][33];
+    const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (i < 2 * c)
+        for (int b = q; b < nblocks; b += 32) s += part[(int64_t)b * 2 * c + i];
+    red[q][col] = s;
+    __syncthreads();
+    if (q == 0 && i < 2 * c) {
+        float t = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) t += red[k][col];
+        if (i < c) dgamma[i] = t;
+        else dbeta[i - c] = t;
     }
 }
 
@@ -331,24 +350,35 @@ int seg3d_layernorm_fwd(const float* x, const float* res, const float* gamma, co
     return SEG3D_OK;
 }
 
+size_t seg3d_layernorm_bwd_workspace_bytes(int64_t m, int32_t c) {
+    if (m < 0 || bad_c(c)) return 0;
+    return (size_t)kLnBwdMaxBlocks * 2 * c * sizeof(float);
+}
+
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        const float* rowscale, int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta, void* stream) {
+                        const float* rowscale, int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     if (m < 0 || bad_c(c) || c > 512 || !dgamma || !dbeta) return SEG3D_EINVAL;
+    if (workspace_bytes < seg3d_layernorm_bwd_workspace_bytes(m, c) || !workspace) return SEG3D_EWORKSPACE;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (m == 0) return SEG3D_OK;
-    if (!dy || !x || !mean || !rstd || !gamma || !dx) return SEG3D_EINVAL;
-    const RowMap rm = row_map(c);
-    unsigned nb = blocks_for(m, 4 * (64 / rm.p) * 8);  // ~8 row batches per wave: fewer global atomics
-    if (nb > 512) nb = 512;
-    const size_t smem = (size_t)2 * c * sizeof(float);
-    if (rm.items == 1)
-        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c, rm,
-                           dx, dgamma, dbeta);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c, rm,
-                           dx, dgamma, dbeta);
+    float* part = static_cast<float*>(workspace);
+    unsigned nb = 0;
+    if (m > 0) {
+        if (!dy || !x || !mean || !rstd || !gamma || !dx) return SEG3D_EINVAL;
+        const RowMap rm = row_map(c);
+        nb = blocks_for(m, 4 * (64 / rm.p) * 4);  // ~4 row batches per wave
+        if (nb > (unsigned)kLnBwdMaxBlocks) nb = kLnBwdMaxBlocks;
+        const size_t smem = (size_t)2 * c * sizeof(float);
+        if (rm.items == 1)
+            hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c,
+                               rm, dx, part);
+        else
+            hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c,
+                               rm, dx, part);
+        SEG3D_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)((2 * c + 31) / 32)), dim3(1024), 0, st, part, (int)nb, c, dgamma,
+                       dbeta);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

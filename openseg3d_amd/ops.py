@@ -494,8 +494,10 @@ class _LayerNormResidualFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty((c,), dtype=torch.float32, device=x.device)
         db = torch.empty((c,), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_layernorm_bwd_workspace_bytes", m, c)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
         _lib.call("seg3d_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rs), m, c, _ptr(dx),
-                  _ptr(dg), _ptr(db), _stream())
+                  _ptr(dg), _ptr(db), _ptr(ws), ws_bytes, _stream())
         return dx, (dy if ctx.has_res else None), dg, db, None, None
 
 
