@@ -323,6 +323,38 @@ int seg3d_knn_query(const float* xyz, int64_t n, const float* new_xyz, int64_t m
                     const int32_t* new_offset, int32_t batch_size, int32_t k, int32_t* idx, float* dist2,
                     void* stream);
 
+/* Grid-accelerated exact kNN (same results and tie rule as seg3d_knn_query) for large clouds, in three steps around
+ * a caller-side sort:
+ *   seg3d_knn_cell_keys   keys[i] = (batch << 48 | cx << 32 | cy << 16 | cz), c* = floor(p / cell) + 32768 (clamped);
+ *   [caller: sort keys, gather points into that order (sorted_xyz [n,3], src_index = original row), unique keys ->
+ *    unique_keys [n_cells], cell_start [n_cells + 1]]
+ *   seg3d_knn_grid_build  open-addressing table unique key -> cell ordinal; capacity = power of two >= 2 n_cells
+ *                         (table_keys: capacity x 8 B, table_vals: capacity x 4 B)
+ *   seg3d_knn_grid_query  per query: cube shells around its cell until the k-th distance is below the shell bound; up to
+ *                         four grids, fine to coarse (lidar density falls as 1/r^2): a query still open after a level's
+ *                         max_ring shells restarts on the next level, and scans its whole segment after the last one.
+ *                         When every level's cell is exactly 8x the previous one, a coarse cell holding > 128 points is
+ *                         searched through its sub-cells, pruned by box distance against the current k-th distance.
+ *                         batch_size <= 255.  `levels` is a HOST array. */
+int seg3d_knn_cell_keys(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell,
+                        int64_t* keys, void* stream);
+int seg3d_knn_grid_build(const int64_t* unique_keys, int64_t n_cells, void* table_keys, int32_t* table_vals,
+                         int64_t capacity, void* stream);
+typedef struct {
+  const float* sorted_xyz;     /* [n,3] points in this level's cell order */
+  const int32_t* src_index;    /* [n] original row of each sorted point */
+  const int32_t* cell_start;   /* [n_cells + 1] */
+  const void* table_keys;      /* capacity x 8 B */
+  const int32_t* table_vals;   /* capacity x 4 B */
+  int64_t capacity;
+  float cell;                  /* metres */
+  int32_t max_ring;            /* shells walked on this level (<= 16) */
+} seg3d_knn_level;
+int seg3d_knn_grid_query(const seg3d_knn_level* levels, int32_t n_levels, const float* new_xyz,
+                         const int32_t* query_order /* queries in level-0 cell order, or NULL */, int64_t m,
+                         const int32_t* offset, const int32_t* new_offset, int32_t batch_size, int32_t k,
+                         int32_t* idx, float* dist2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

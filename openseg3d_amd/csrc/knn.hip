@@ -94,6 +94,205 @@ __global__ __launch_bounds__(kThreads) void knn_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Grid-accelerated exact variant (same results, same tie rule) for large clouds: the 180k x 180k fusion query costs
+// 46 ms by brute force.  Points are binned into cubic cells (key = batch | cx | cy | cz, 16 bits each), sorted by key
+// (caller: torch.sort), the non-empty cells go into an open-addressing table, and every query walks the cube shells
+// r = 0, 1, 2, .. around its own cell until its K-th distance is strictly below (r * cell)^2 -- every point not yet
+// visited is at least that far.  Queries that have not converged after kMaxRing shells (isolated points) scan their
+// whole batch segment.  Entries are ordered by (d2, original index), i.e. exactly the brute-force order.
+constexpr int kCellBias = 32768;
+
+__device__ __forceinline__ int cell_of(float p, float inv_cell) {
+    const float f = floorf(p * inv_cell);
+    const int c = (int)fminf(fmaxf(f, -32768.f), 32767.f) + kCellBias;
+    return c;
+}
+
+__device__ __forceinline__ unsigned long long cell_key(int b, int cx, int cy, int cz) {
+    return ((((unsigned long long)b << 16 | (unsigned)cx) << 16 | (unsigned)cy) << 16) | (unsigned)cz;
+}
+
+__global__ __launch_bounds__(kThreads) void knn_cell_keys(const float* __restrict__ xyz, int n, const int32_t* __restrict__ offset,
+                                                          int b, float inv_cell, int64_t* __restrict__ keys) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int seg = segment_of(i, offset, b);
+    keys[i] = (int64_t)cell_key(seg, cell_of(xyz[3 * (int64_t)i], inv_cell), cell_of(xyz[3 * (int64_t)i + 1], inv_cell),
+                                cell_of(xyz[3 * (int64_t)i + 2], inv_cell));
+}
+
+__global__ __launch_bounds__(kThreads) void knn_table_insert(const int64_t* __restrict__ ukeys, int n_cells,
+                                                             unsigned long long* __restrict__ tkeys,
+                                                             int32_t* __restrict__ tvals, unsigned cap_mask) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_cells) return;
+    const unsigned long long key = (unsigned long long)ukeys[i];
+    unsigned slot = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & cap_mask;
+    for (;;) {  // unique keys, table at most half full: terminates
+        const unsigned long long prev = atomicCAS(&tkeys[slot], ~0ull, key);
+        if (prev == ~0ull) {
+            tvals[slot] = i;
+            return;
+        }
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
+struct GridLevel {
+    const float* sxyz;        // points in this level's cell order
+    const int32_t* src;       // original row of each sorted point
+    const int32_t* cell_start;
+    const unsigned long long* tkeys;
+    const int32_t* tvals;
+    unsigned cap_mask;
+    float cell;
+    int max_ring;
+};
+struct GridLevels {
+    GridLevel lv[4];
+    int n;
+    int nested;  // every level's cell is exactly 8x the previous one: dense cells may be searched through their sub-cells
+};
+
+constexpr int kDenseCell = 128;  // points; above this a cell is searched through the next finer level
+
+// Lidar density falls as 1/r^2: no single cell size serves both the ground rings next to the sensor and the walls at
+// 70 m.  Up to four grids (fine -> coarse); a query climbs to the next level (list reset, shells restart) when its
+// K-th distance is still open after max_ring shells, and scans its whole segment after the last level.  A coarse cell
+// that holds many points is not scanned but searched through its 8^3 sub-cells of the next finer level, skipping
+// sub-cells whose box is farther than the current K-th distance -- so a dense clump next to a sparse query costs a
+// thin slice of it, not all of it.
+template <int K>
+struct KnnState {
+    float bd[K];
+    int32_t bi[K];
+    float qx, qy, qz;
+    int seg;
+
+    __device__ __forceinline__ void reset(int seg_start) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            bd[j] = 1e10f;
+            bi[j] = seg_start;
+        }
+    }
+    __device__ __forceinline__ void offer(const GridLevel& L, int c) {  // candidate at sorted position c of level L
+        const float dx = qx - L.sxyz[3 * (int64_t)c], dy = qy - L.sxyz[3 * (int64_t)c + 1], dz = qz - L.sxyz[3 * (int64_t)c + 2];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 > bd[K - 1]) return;
+        const int32_t id = L.src[c];
+        if (d2 == bd[K - 1] && id > bi[K - 1]) return;
+        float cd = d2;
+        int32_t ci = id;
+        bool shifting = false;  // ordered by (d2, original index): once inserted, everything behind moves down one slot
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (shifting || cd < bd[j] || (cd == bd[j] && ci < bi[j])) {
+                shifting = true;
+                const float td = bd[j];
+                const int32_t ti = bi[j];
+                bd[j] = cd;
+                bi[j] = ci;
+                cd = td;
+                ci = ti;
+            }
+        }
+    }
+    // squared distance from the query to the box of (biased) cell (x, y, z) of size s
+    __device__ __forceinline__ float box_d2(int x, int y, int z, float s) const {
+        const float lx = (float)(x - kCellBias) * s, ly = (float)(y - kCellBias) * s, lz = (float)(z - kCellBias) * s;
+        const float ex = fmaxf(fmaxf(lx - qx, qx - (lx + s)), 0.f);
+        const float ey = fmaxf(fmaxf(ly - qy, qy - (ly + s)), 0.f);
+        const float ez = fmaxf(fmaxf(lz - qz, qz - (lz + s)), 0.f);
+        return (ex * ex + ey * ey) + ez * ez;
+    }
+    template <int L>
+    __device__ void visit(const GridLevels& g, int x, int y, int z) {
+        if ((unsigned)x > 65535u || (unsigned)y > 65535u || (unsigned)z > 65535u) return;
+        const GridLevel& lv = g.lv[L];
+        const unsigned long long key = cell_key(seg, x, y, z);
+        unsigned slot = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & lv.cap_mask;
+        for (;;) {
+            const unsigned long long tk = lv.tkeys[slot];
+            if (tk == key) break;
+            if (tk == ~0ull) return;  // empty cell
+            slot = (slot + 1) & lv.cap_mask;
+        }
+        const int ci = lv.tvals[slot];
+        const int c0 = lv.cell_start[ci], c1 = lv.cell_start[ci + 1];
+        if constexpr (L > 0) {
+            if (g.nested && c1 - c0 > kDenseCell) {
+                const float s = g.lv[L - 1].cell;
+                // the conservative factor keeps a sub-cell whose box distance rounds just above the K-th distance
+                const int fx = (x - kCellBias) * 8 + kCellBias, fy = (y - kCellBias) * 8 + kCellBias, fz = (z - kCellBias) * 8 + kCellBias;
+                for (int dz = 0; dz < 8; ++dz)
+                    for (int dy = 0; dy < 8; ++dy)
+                        for (int dx = 0; dx < 8; ++dx)
+                            if (box_d2(fx + dx, fy + dy, fz + dz, s) * 0.99999f <= bd[K - 1]) visit<L - 1>(g, fx + dx, fy + dy, fz + dz);
+                return;
+            }
+        }
+        for (int c = c0; c < c1; ++c) offer(lv, c);
+    }
+    template <int L>
+    __device__ bool search_level(const GridLevels& g, int seg_start) {  // true when the K-th distance is settled
+        const GridLevel& lv = g.lv[L];
+        const float inv_cell = 1.0f / lv.cell;
+        const int cx = cell_of(qx, inv_cell), cy = cell_of(qy, inv_cell), cz = cell_of(qz, inv_cell);
+        reset(seg_start);
+        for (int r = 0; r <= lv.max_ring; ++r) {
+            for (int dz = -r; dz <= r; ++dz)
+                for (int dy = -r; dy <= r; ++dy) {
+                    if (dz == -r || dz == r || dy == -r || dy == r) {
+                        for (int dx = -r; dx <= r; ++dx) visit<L>(g, cx + dx, cy + dy, cz + dz);
+                    } else {
+                        visit<L>(g, cx - r, cy + dy, cz + dz);
+                        if (r > 0) visit<L>(g, cx + r, cy + dy, cz + dz);
+                    }
+                }
+            // every unvisited point lies outside the cube of r cells around the query's cell: farther than r * cell
+            const float bound = (float)r * lv.cell;
+            if (bd[K - 1] < bound * bound * 0.999999f) return true;
+        }
+        return false;
+    }
+};
+
+template <int K>
+__global__ __launch_bounds__(kThreads) void knn_grid_kernel(GridLevels g, const float* __restrict__ qxyz,
+                                                            const int32_t* __restrict__ qorder,
+                                                            const int32_t* __restrict__ offset,
+                                                            const int32_t* __restrict__ new_offset, int b, int m, int k,
+                                                            int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= m) return;
+    // queries are walked in (finest) cell order when the caller provides it: the lanes of a wave then visit the same
+    // cells in the same order (uniform trip counts, identical candidate addresses)
+    const int q = qorder ? qorder[t] : t;
+    KnnState<K> st;
+    st.seg = segment_of(q, new_offset, b);
+    const int seg_start = st.seg == 0 ? 0 : offset[st.seg - 1], seg_end = offset[st.seg];
+    st.qx = qxyz[3 * (int64_t)q];
+    st.qy = qxyz[3 * (int64_t)q + 1];
+    st.qz = qxyz[3 * (int64_t)q + 2];
+    bool done = st.template search_level<0>(g, seg_start);
+    if (!done && g.n > 1) done = st.template search_level<1>(g, seg_start);
+    if (!done && g.n > 2) done = st.template search_level<2>(g, seg_start);
+    if (!done && g.n > 3) done = st.template search_level<3>(g, seg_start);
+    if (!done) {  // isolated query: exact scan of the whole segment (same order relation)
+        st.reset(seg_start);
+        for (int c = seg_start; c < seg_end; ++c) st.offer(g.lv[0], c);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < k) {
+            idx_out[(int64_t)q * k + j] = st.bi[j];
+            d2_out[(int64_t)q * k + j] = st.bd[j];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int seg3d_knn_query(const float* xyz, int64_t n, const float* new_xyz, int64_t m, const int32_t* offset,
@@ -114,6 +313,71 @@ extern "C" int seg3d_knn_query(const float* xyz, int64_t n, const float* new_xyz
     else if (k <= 32) SEG3D_KNN(32);
     else SEG3D_KNN(64);
 #undef SEG3D_KNN
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+/* Grid-accelerated exact kNN, three steps around a caller-side sort (see knn.hip):
+ *   keys[i] = cell key of xyz row i (batch | cx | cy | cz);  table = open-addressing map of the unique keys;
+ *   query over the points gathered into cell order. */
+extern "C" int seg3d_knn_cell_keys(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell,
+                                   int64_t* keys, void* stream) {
+    if (n < 0 || batch_size <= 0 || batch_size > 255 || !(cell > 0.f) || n >= (int64_t)0x7FFFFFF0) return SEG3D_EINVAL;
+    if (n == 0) return SEG3D_OK;
+    if (!xyz || !offset || !keys) return SEG3D_EINVAL;
+    hipLaunchKernelGGL(knn_cell_keys, dim3((unsigned)ceil_div64(n, kThreads)), dim3(kThreads), 0, as_stream(stream), xyz, (int)n,
+                       offset, batch_size, 1.0f / cell, keys);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+extern "C" int seg3d_knn_grid_build(const int64_t* unique_keys, int64_t n_cells, void* table_keys, int32_t* table_vals,
+                                    int64_t capacity, void* stream) {
+    if (n_cells < 0 || capacity < 2 * n_cells || capacity <= 0 || (capacity & (capacity - 1)) || capacity > (1ll << 30))
+        return SEG3D_EINVAL;
+    if (!table_keys || !table_vals || (n_cells > 0 && !unique_keys)) return SEG3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(table_keys, 0xFF, (size_t)capacity * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
+    if (n_cells == 0) return SEG3D_OK;
+    hipLaunchKernelGGL(knn_table_insert, dim3((unsigned)ceil_div64(n_cells, kThreads)), dim3(kThreads), 0, st, unique_keys,
+                       (int)n_cells, static_cast<unsigned long long*>(table_keys), table_vals, (unsigned)(capacity - 1));
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+extern "C" int seg3d_knn_grid_query(const seg3d_knn_level* levels, int32_t n_levels, const float* new_xyz,
+                                    const int32_t* query_order, int64_t m, const int32_t* offset,
+                                    const int32_t* new_offset, int32_t batch_size, int32_t k, int32_t* idx, float* dist2,
+                                    void* stream) {
+    if (m < 0 || batch_size <= 0 || batch_size > 255 || k <= 0 || k > 64 || n_levels < 1 || n_levels > 4 || !levels ||
+        m >= (int64_t)0x7FFFFFF0)
+        return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!new_xyz || !offset || !new_offset || !idx || !dist2) return SEG3D_EINVAL;
+    GridLevels g;
+    g.n = n_levels;
+    g.nested = 1;
+    for (int l = 1; l < n_levels; ++l)
+        if (fabsf(levels[l].cell - 8.0f * levels[l - 1].cell) > 1e-6f * levels[l].cell) g.nested = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const seg3d_knn_level& a = levels[l];
+        if (!a.sorted_xyz || !a.src_index || !a.cell_start || !a.table_keys || !a.table_vals || a.capacity <= 0 ||
+            (a.capacity & (a.capacity - 1)) || !(a.cell > 0.f) || a.max_ring < 0 || a.max_ring > 16)
+            return SEG3D_EINVAL;
+        g.lv[l] = GridLevel{a.sorted_xyz, a.src_index, a.cell_start, static_cast<const unsigned long long*>(a.table_keys),
+                            a.table_vals, (unsigned)(a.capacity - 1), a.cell, a.max_ring};
+    }
+    hipStream_t st = as_stream(stream);
+    const unsigned nb = (unsigned)ceil_div64(m, kThreads);
+#define SEG3D_KNNG(KK)                                                                                                  \
+    hipLaunchKernelGGL(knn_grid_kernel<KK>, dim3(nb), dim3(kThreads), 0, st, g, new_xyz, query_order, offset, new_offset,  \
+                       batch_size, (int)m, (int)k, idx, dist2)
+    if (k == 1) SEG3D_KNNG(1);
+    else if (k <= 4) SEG3D_KNNG(4);
+    else if (k <= 16) SEG3D_KNNG(16);
+    else if (k <= 32) SEG3D_KNNG(32);
+    else SEG3D_KNNG(64);
+#undef SEG3D_KNNG
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

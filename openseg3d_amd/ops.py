@@ -873,6 +873,20 @@ def voxel_avg_pooling(feats, coords, counts):
 
 
 # ------------------------------------------------------------------------------------------ kNN
+KNN_GRID_MIN_POINTS = int(os.environ.get("SEG3D_KNN_GRID_MIN", "8192"))  # below this the brute-force kernel is faster
+# (cell size in metres, shells walked) fine -> coarse; exactness does not depend on the choice
+# cells in a ratio of exactly 8 let the kernel search dense coarse cells through their sub-cells
+KNN_GRID_LEVELS = ((0.05, 2), (0.4, 3), (3.2, 4))  # measured best on the multi-sweep bench (tools/knn_bench_model.py)
+if os.environ.get("SEG3D_KNN_LEVELS"):  # e.g. "0.1:2,0.5:3,3.0:4"
+    KNN_GRID_LEVELS = tuple((float(a), int(b)) for a, b in (t.split(":") for t in os.environ["SEG3D_KNN_LEVELS"].split(",")))
+
+
+class _KnnLevel(ctypes.Structure):  # seg3d_knn_level
+    _fields_ = [("sorted_xyz", ctypes.c_void_p), ("src_index", ctypes.c_void_p), ("cell_start", ctypes.c_void_p),
+                ("table_keys", ctypes.c_void_p), ("table_vals", ctypes.c_void_p), ("capacity", ctypes.c_int64),
+                ("cell", ctypes.c_float), ("max_ring", ctypes.c_int32)]
+
+
 def knn_query(nsample, xyz, new_xyz, offset, new_offset):
     """``seg3d.ops.knn_query`` (knn_query.py:7-24): (idx int32 [m, nsample], dist float32 [m, nsample] = sqrt(d2)).
     xyz / new_xyz: contiguous float32 [*, 3]; offset / new_offset: cumulative int32 counts per sample.
@@ -890,8 +904,41 @@ def knn_query(nsample, xyz, new_xyz, offset, new_offset):
     # what happens when DeepFusionBlock passes [N, 6] points (SURVEY 2.2 "latent bug").  Reproduced as is.
     n, m = xyz.shape[0], new_xyz.shape[0]
     off, noff = _i32c(offset), _i32c(new_offset)
-    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
-    d2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
+    if n >= KNN_GRID_MIN_POINTS and nsample <= 64 and off.shape[0] <= 255:
+        # exact grid search (same results): per level bin, sort by cell, table of non-empty cells; shell walk per query
+        dev = xyz.device
+        xyz3 = xyz.reshape(-1)[: 3 * n].view(n, 3)
+        keep, levels = [], (_KnnLevel * len(KNN_GRID_LEVELS))()
+        for li, (cell, max_ring) in enumerate(KNN_GRID_LEVELS):
+            keys = torch.empty((n,), dtype=torch.int64, device=dev)
+            _lib.call("seg3d_knn_cell_keys", _ptr(xyz3), n, _ptr(off), off.shape[0], float(cell), _ptr(keys), _stream())
+            skeys, order = torch.sort(keys)
+            sorted_xyz = xyz3.index_select(0, order).contiguous()
+            src_index = order.to(torch.int32)
+            ukeys, counts = torch.unique_consecutive(skeys, return_counts=True)
+            n_cells = int(ukeys.shape[0])
+            cell_start = torch.zeros((n_cells + 1,), dtype=torch.int32, device=dev)
+            cell_start[1:] = torch.cumsum(counts, 0)
+            cap = 1 << max(4, (2 * n_cells - 1).bit_length())
+            tkeys = torch.empty((cap,), dtype=torch.int64, device=dev)
+            tvals = torch.empty((cap,), dtype=torch.int32, device=dev)
+            _lib.call("seg3d_knn_grid_build", _ptr(ukeys), n_cells, _ptr(tkeys), _ptr(tvals), cap, _stream())
+            keep.append((sorted_xyz, src_index, cell_start, tkeys, tvals))
+            levels[li] = _KnnLevel(sorted_xyz.data_ptr(), src_index.data_ptr(), cell_start.data_ptr(), tkeys.data_ptr(),
+                                   tvals.data_ptr(), cap, float(cell), int(max_ring))
+        if new_xyz.data_ptr() == xyz.data_ptr() and m == n:
+            qorder = keep[0][1]  # self-query: the points' own finest-level cell order
+        else:
+            q3 = new_xyz.reshape(-1)[: 3 * m].view(m, 3)
+            qkeys = torch.empty((m,), dtype=torch.int64, device=dev)
+            _lib.call("seg3d_knn_cell_keys", _ptr(q3), m, _ptr(noff), noff.shape[0], float(KNN_GRID_LEVELS[0][0]), _ptr(qkeys),
+                      _stream())
+            qorder = torch.sort(qkeys)[1].to(torch.int32)
+        _lib.call("seg3d_knn_grid_query", ctypes.cast(levels, ctypes.c_void_p), len(KNN_GRID_LEVELS), _ptr(new_xyz),
+                  _ptr(qorder), m, _ptr(off), _ptr(noff), off.shape[0], int(nsample), _ptr(idx), _ptr(d2), _stream())
+        return idx, torch.sqrt(d2)
     _lib.call("seg3d_knn_query", _ptr(xyz), n, _ptr(new_xyz), m, _ptr(off), _ptr(noff), off.shape[0], int(nsample),
               _ptr(idx), _ptr(d2), _stream())
     return idx, torch.sqrt(d2)

@@ -467,3 +467,38 @@ def test_segformer_multi_sweep_fusion_matches_reference_model(dev, golden_dir):
     res = model(batch)
     (res["point_out"].square().mean() + res["voxel_out"].mean() + res["aux_voxel_out"].mean()).backward()
     assert not [k for k, p in model.named_parameters() if p.grad is None]
+
+
+@pytest.mark.parametrize("k", [1, 16])
+def test_knn_grid_matches_brute_force(dev, monkeypatch, k):
+    """The grid-accelerated search must return exactly what the brute-force kernel returns (indices and distances),
+    including duplicate points (ties by ascending index), isolated queries (segment-scan fallback) and two batches."""
+    from openseg3d_amd import ops
+    rs = np.random.RandomState(3)
+    def cloud(n):
+        ground = np.stack([rs.uniform(-40, 40, n // 2), rs.uniform(-40, 40, n // 2), rs.normal(0, 0.05, n // 2)], 1)
+        blob = rs.normal(0, 0.3, (n // 4, 3)) + np.array([5.0, -3.0, 1.0])
+        far = rs.uniform(-70, 70, (n - n // 2 - n // 4, 3)) * np.array([1, 1, 0.03])
+        pts = np.concatenate([ground, blob, far]).astype(np.float32)
+        pts[10:20] = pts[0:10]          # exact duplicates
+        pts[-1] = [900.0, 900.0, 50.0]  # isolated point: needs the fallback
+        return pts
+    a, b = cloud(20000), cloud(9000)
+    xyz = torch.from_numpy(np.concatenate([a, b])).to(dev)
+    off = torch.tensor([a.shape[0], a.shape[0] + b.shape[0]], dtype=torch.int32, device=dev)
+    monkeypatch.setattr(ops, "KNN_GRID_MIN_POINTS", 1 << 40)
+    i0, d0 = ops.knn_query(k, xyz, xyz, off, off)
+    monkeypatch.setattr(ops, "KNN_GRID_MIN_POINTS", 1)
+    for levels in (ops.KNN_GRID_LEVELS, ((0.5, 2),), ((0.3, 1), (3.0, 2)), ((0.02, 2), (0.16, 3), (1.28, 3), (10.24, 3))):
+        monkeypatch.setattr(ops, "KNN_GRID_LEVELS", levels)
+        i1, d1 = ops.knn_query(k, xyz, xyz, off, off)
+        assert torch.equal(i0, i1), levels
+        assert torch.equal(d0, d1), levels
+    # separate query set (not the points themselves): goes through the query-side cell sort
+    qs = xyz[::7].contiguous() + 0.01
+    qoff = torch.tensor([(a.shape[0] + 6) // 7, qs.shape[0]], dtype=torch.int32, device=dev)
+    monkeypatch.setattr(ops, "KNN_GRID_MIN_POINTS", 1 << 40)
+    i2, d2 = ops.knn_query(k, xyz, qs, off, qoff)
+    monkeypatch.setattr(ops, "KNN_GRID_MIN_POINTS", 1)
+    i3, d3 = ops.knn_query(k, xyz, qs, off, qoff)
+    assert torch.equal(i2, i3) and torch.equal(d2, d3)
