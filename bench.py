@@ -221,7 +221,8 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True)
     labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
-    ce = torch.nn.functional.cross_entropy
+    from openseg3d_amd import ops as _ops
+    ce = _ops.cross_entropy  # seg3d_cross_entropy_fwd/bwd (torch's nll_loss reduce kernels are single-block)
 
     def fwd_step(i):
         j = i % len(resident)

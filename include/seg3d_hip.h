@@ -355,6 +355,19 @@ int seg3d_knn_grid_query(const seg3d_knn_level* levels, int32_t n_levels, const 
                          const int32_t* offset, const int32_t* new_offset, int32_t batch_size, int32_t k,
                          int32_t* idx, float* dist2, void* stream);
 
+/*
+ * SURVEY 8(f)  cross-entropy term of the training loss (tools/train.py: nn.CrossEntropyLoss(ignore_index=...), mean
+ * over the counted rows) on logits [n, c] with int64 labels; rows whose label is ignore_index (or outside [0, c))
+ * contribute nothing.  forward: lse [n] kept for backward, stats = {mean loss, count}; backward: dlogits =
+ * (softmax - onehot) * grad_out / count.  Deterministic (per-block partials, fixed-order finalize).
+ */
+size_t seg3d_cross_entropy_workspace_bytes(int64_t n);
+int seg3d_cross_entropy_fwd(const float* logits, const int64_t* labels, int64_t n, int32_t c, int64_t ignore_index,
+                            float* lse, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+int seg3d_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* lse, const float* stats,
+                            const float* grad_out, int64_t n, int32_t c, int64_t ignore_index, float* dlogits,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -942,3 +942,40 @@ def knn_query(nsample, xyz, new_xyz, offset, new_offset):
     _lib.call("seg3d_knn_query", _ptr(xyz), n, _ptr(new_xyz), m, _ptr(off), _ptr(noff), off.shape[0], int(nsample),
               _ptr(idx), _ptr(d2), _stream())
     return idx, torch.sqrt(d2)
+
+
+# ------------------------------------------------------------------------------------------ loss
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        x = _f32c(logits)
+        n, c = x.shape
+        lab = labels.contiguous()
+        lse = torch.empty((n,), dtype=torch.float32, device=x.device)
+        stats = torch.empty((2,), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_cross_entropy_workspace_bytes", n)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        _lib.call("seg3d_cross_entropy_fwd", _ptr(x), _ptr(lab), n, c, int(ignore_index), _ptr(lse), _ptr(stats), _ptr(ws),
+                  ws_bytes, _stream())
+        ctx.save_for_backward(x, lab, lse, stats)
+        ctx.ignore_index = int(ignore_index)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lab, lse, stats = ctx.saved_tensors
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        gg = _f32c(g.reshape(1))
+        _lib.call("seg3d_cross_entropy_bwd", _ptr(x), _ptr(lab), _ptr(lse), _ptr(stats), _ptr(gg), n, c, ctx.ignore_index,
+                  _ptr(dx), _stream())
+        return dx, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """``F.cross_entropy(logits, labels, ignore_index=...)`` (mean reduction) for float32 [n, C] logits and int64 labels
+    on the GPU, in one pass each way; anything else goes to torch."""
+    if not (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64
+            and labels.dim() == 1 and labels.shape[0] == logits.shape[0] and logits.shape[1] <= 4096):
+        return torch.nn.functional.cross_entropy(logits, labels, ignore_index=ignore_index)
+    return _CrossEntropyFn.apply(logits, labels, ignore_index)

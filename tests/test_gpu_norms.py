@@ -131,3 +131,24 @@ def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
         ye = ops.batch_norm_act(x.to(dev), bn.eval(), relu=relu, res=r.to(dev) if with_res else None)
         yre = ref_fwd(ref.eval(), x.double(), r.double())
     assert float((ye.cpu().double() - yre).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("n,c", [(50000, 22), (1, 22), (777, 5)])
+def test_cross_entropy_matches_torch(n, c):
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 3
+    y = torch.randint(0, c, (n,))
+    y[::7] = 255  # ignored rows
+    xr = x.double().requires_grad_()
+    lr = torch.nn.functional.cross_entropy(xr, y, ignore_index=255)
+    (lr * 1.7).backward()
+    xg = x.to(dev).requires_grad_()
+    lg = ops.cross_entropy(xg, y.to(dev), ignore_index=255)
+    (lg * 1.7).backward()
+    if bool((y != 255).any()):
+        assert abs(float(lg) - float(lr)) < 1e-5 * max(1.0, abs(float(lr)))
+        assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 1e-7 + 1e-5 * float(xr.grad.abs().max())
+    else:
+        assert float(lg) == 0.0 and float(xg.grad.abs().max()) == 0.0
