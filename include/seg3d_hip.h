@@ -181,7 +181,8 @@ size_t seg3d_linear_packed_bytes(int32_t cin, int32_t cout, int32_t transpose);
 int seg3d_linear_pack_weight(const float* weight, int32_t cin, int32_t cout, int32_t transpose,
                              void* w_packed, void* stream);
 int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
-                     int32_t cin, int32_t cout, float* y, void* stream);
+                     const float* addend /* [m, cout] added in the epilogue, or NULL */, int32_t cin, int32_t cout,
+                     float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /

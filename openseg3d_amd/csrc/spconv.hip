@@ -16,8 +16,8 @@
 size_t spconv_split_packed_bytes(int cin_op, int cout_op, int kk);
 int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transpose, int flip, void* w_packed,
                       hipStream_t st);
-int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
-                     int cout, float* y, hipStream_t st);
+int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                     const float* addend, int cin, int cout, float* y, hipStream_t st);
 size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
                        void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -315,7 +315,7 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
     if (m_out == 0) return SEG3D_OK;
     if (!x || !nbr || !y) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (pack_flags & 4) return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, cin, cout, y, st);
+    if (pack_flags & 4) return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, nullptr, cin, cout, y, st);
     return dispatch_fwd_f32(x, nbr, m_out, static_cast<const float*>(w_packed_v), bias, cin, cout, y, st);
 }
 

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
 template <int NBT, int RB, bool DENSE>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
-                                                              const float* __restrict__ bias, int cin, int cout,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ addend, int cin, int cout,
                                                               float* __restrict__ y) {
     constexpr int kW = 4;
     constexpr int kSlot = NBT * 128;  // uint4 per staged chunk (NBT x {hi, lo} x 64 lanes)
@@ -298,22 +299,28 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             const int64_t orow = row0 + rb * 16 + g * 4 + r;
             if (orow < m_out) {
                 float* yr = y + orow * cout + nb0 * 16 + c16;
+                if (addend) {  // y = x W^T + b + addend: a second gradient path summed in the epilogue
+                    const float* ar = addend + orow * cout + nb0 * 16 + c16;
 #pragma unroll
-                for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r];
+                    for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r] + ar[n * 16];
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r];
+                }
             }
         }
 }
 
 template <int NBT, int RB>
-int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin, int cout,
-                 float* y, hipStream_t st) {
+int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const float* addend,
+                 int cin, int cout, float* y, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
     if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, cin, cout, y);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, cin, cout, y);
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, cin, cout, y);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, cin, cout, y);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -335,8 +342,8 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
     return SEG3D_OK;
 }
 
-int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, int cin,
-                     int cout, float* y, hipStream_t st) {
+int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                     const float* addend, int cin, int cout, float* y, hipStream_t st) {
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
     // (19k, 7k) and wide channels and run better on twice as many 96-column workgroups (measured per layer,
     // profiles/README.md); narrower tiles re-gather the rows too often.
@@ -353,12 +360,12 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
         if (w > 0 && nb % w == 0) pick = w;
     }
     switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, cin, cout, y, st);
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
     }
 }
 
@@ -389,12 +396,12 @@ int seg3d_linear_pack_weight(const float* weight, int32_t cin, int32_t cout, int
     return spconv_split_pack(weight, cin, cout, 1, transpose ? 1 : 0, 0, w_packed, as_stream(stream));
 }
 
-int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias, int32_t cin, int32_t cout,
-                     float* y, void* stream) {
+int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias, const float* addend, int32_t cin,
+                     int32_t cout, float* y, void* stream) {
     if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
-    return spconv_split_fwd(x, nullptr, m, w_packed, bias, cin, cout, y, as_stream(stream));
+    return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, cin, cout, y, as_stream(stream));
 }
 
 }  // extern "C"

@@ -360,9 +360,9 @@ def _linear_apply_f32(x, packed, bias, cin, cout):
     return y
 
 
-def _linear_apply(x, packed, bias, cin, cout):
+def _linear_apply(x, packed, bias, cin, cout, addend=None):
     y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
-    _lib.call("seg3d_linear_fwd", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), cin, cout, _ptr(y), _stream())
+    _lib.call("seg3d_linear_fwd", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), _ptr(addend), cin, cout, _ptr(y), _stream())
     return y
 
 
@@ -744,8 +744,7 @@ class _AttnInProjFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dpos = d_xp
             if ctx.needs_input_grad[0]:
-                dx = _linear_apply(dv, _linear_pack(w_in[2 * c:], 1), None, c, c)
-                dx += d_xp
+                dx = _linear_apply(dv, _linear_pack(w_in[2 * c:], 1), None, c, c, addend=d_xp)  # both paths in one pass
         if ctx.needs_input_grad[2]:
             dw = torch.empty((3 * c, c), dtype=torch.float32, device=x.device)
             db = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
