@@ -73,10 +73,10 @@ def conv_roofline(model, batch, dev):
     records = []
     orig = ops._conv_apply
 
-    def timed(x, nbr, w_packed, bias, cin, cout):  # noqa: E306
+    def timed(x, nbr, w_packed, bias, cin, cout, order=None):  # noqa: E306
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig(x, nbr, w_packed, bias, cin, cout)
+        y = orig(x, nbr, w_packed, bias, cin, cout, order)
         e1.record()
         records.append((nbr, cin, cout, e0, e1))
         return y

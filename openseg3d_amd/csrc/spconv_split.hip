@@ -7,7 +7,9 @@
 // rate.  Effect on the full model: max |logit error| 9e-6 against the 1e-3 budget.
 //
 // Tile: 4 waves x (RB x 16) output rows x (NBT x 16) columns.  Work is a stream of chunks
-// (active kernel offset k, 32 input channels).  Per chunk the workgroup copies the pre-split W_k fragments
+// (active kernel offset k, 32 input channels).  An optional row order lets the caller group output rows that share
+// their set of active offsets (strided / inverse convs: the set is fixed by the row's coordinate parity, 1-8 of 27),
+// so that a tile visits only those offsets instead of all 27.  Per chunk the workgroup copies the pre-split W_k fragments
 // (NBT x 2 KiB, contiguous in the packed stream) straight into a double-buffered LDS slot with
 // register-staged 16-B loads, every wave gathers its neighbour rows (32 B per lane), splits them in
 // registers and issues RB x NBT x 3 v_mfma_f32_16x16x32_bf16.  The W loads and the gather of chunk c+1 are
@@ -113,7 +115,8 @@ template <int NBT, int RB, bool DENSE>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
                                                               const float* __restrict__ bias,
-                                                              const float* __restrict__ addend, int cin, int cout,
+                                                              const float* __restrict__ addend,
+                                                              const int32_t* __restrict__ row_order, int cin, int cout,
                                                               float* __restrict__ y) {
     constexpr int kW = 4;
     constexpr int kSlot = NBT * 128;  // uint4 per staged chunk (NBT x {hi, lo} x 64 lanes)
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
     // ---- which offsets does this tile touch?  (27 independent loads, then ballots)
     uint32_t my_mask = 0;
     {
-        const int64_t r = row0 + (lane & (RB * 16 - 1));
-        const bool ok = r < m_out;
-        const int64_t rc = ok ? r : last_row;
+        const int64_t pos = row0 + (lane & (RB * 16 - 1));  // tile position -> output row (optional processing order)
+        const bool ok = pos < m_out;
+        const int64_t rc = ok ? (row_order ? (int64_t)row_order[pos] : pos) : last_row;
         if (DENSE) {  // dense rows (Linear layer): one "offset", neighbour of row r is row r
             my_mask = 1u;
         } else {
@@ -163,9 +166,9 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         bool grow_ok[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            const int64_t r = row0 + rb * 16 + c16;
-            grow_ok[rb] = r < m_out;
-            grow[rb] = grow_ok[rb] ? r : last_row;
+            const int64_t pos = row0 + rb * 16 + c16;
+            grow_ok[rb] = pos < m_out;
+            grow[rb] = grow_ok[rb] ? (row_order ? (int64_t)row_order[pos] : pos) : last_row;
         }
         // neighbour rows of offset k for this lane's RB rows (raw loads; the caller decides when to look at them)
         auto fetch_idx = [&](int k, int32_t* idx) {
@@ -296,8 +299,9 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t orow = row0 + rb * 16 + g * 4 + r;
-            if (orow < m_out) {
+            const int64_t opos = row0 + rb * 16 + g * 4 + r;
+            if (opos < m_out) {
+                const int64_t orow = row_order ? (int64_t)row_order[opos] : opos;
                 float* yr = y + orow * cout + nb0 * 16 + c16;
                 if (addend) {  // y = x W^T + b + addend: a second gradient path summed in the epilogue
                     const float* ar = addend + orow * cout + nb0 * 16 + c16;
@@ -313,14 +317,14 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 
 template <int NBT, int RB>
 int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const float* addend,
-                 int cin, int cout, float* y, hipStream_t st) {
+                 const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
     if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, cin, cout, y);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y);
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, cin, cout, y);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -343,7 +347,7 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
 }
 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                     const float* addend, int cin, int cout, float* y, hipStream_t st) {
+                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
     // (19k, 7k) and wide channels and run better on twice as many 96-column workgroups (measured per layer,
     // profiles/README.md); narrower tiles re-gather the rows too often.
@@ -360,12 +364,12 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
         if (w > 0 && nb % w == 0) pick = w;
     }
     switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, cin, cout, y, st);
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
     }
 }
 
@@ -401,7 +405,7 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
     if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
-    return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, cin, cout, y, as_stream(stream));
+    return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, as_stream(stream));
 }
 
 }  // extern "C"

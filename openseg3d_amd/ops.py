@@ -279,11 +279,11 @@ def pack_weight(weight, flags):
     return PackedWeight(out, flags)
 
 
-def _conv_apply(x, nbr, packed, bias, cin, cout):
+def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
     _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
-              cin, cout, _ptr(y), _stream())
+              cin, cout, _ptr(y), _ptr(order), _stream())
     return y
 
 
@@ -291,14 +291,14 @@ class _SparseConvFn(torch.autograd.Function):
     """y[r] = bias + sum_k x[nbr[k][r]] . W_k ; nbr_t is the same pair list keyed by input row."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nbr, nbr_t, t_flags, packed):
+    def forward(ctx, x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t):
         x = _f32c(x)
         cout, cin = weight.shape[0], weight.shape[-1]
         if packed is None:
             packed = pack_weight(weight, PACK_FWD)
-        y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout)
+        y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout, order)
         ctx.save_for_backward(x, weight)
-        ctx.nbr, ctx.nbr_t, ctx.t_flags, ctx.has_bias = nbr, nbr_t, t_flags, bias is not None
+        ctx.nbr, ctx.nbr_t, ctx.t_flags, ctx.has_bias, ctx.order_t = nbr, nbr_t, t_flags, bias is not None, order_t
         return y
 
     @staticmethod
@@ -309,7 +309,7 @@ class _SparseConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight, ctx.t_flags)
-            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin)
+            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, dtype=torch.float32)
             ws_bytes = _lib.query("seg3d_spconv_wgrad_workspace_bytes", dy.shape[0], cin, cout)
@@ -318,12 +318,14 @@ class _SparseConvFn(torch.autograd.Function):
                       _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, _stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None):
+def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None, order=None, order_t=None):
+    """order / order_t: optional processing orders (int32 permutations) of the rows of nbr / nbr_t -- see
+    SiteLevel.parity_order; they change scheduling only, never results."""
     _need_gpu(x, weight, nbr)
-    return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed)
+    return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t)
 
 
 # ------------------------------------------------------------------------------------------ a6/a22 dense layers

@@ -37,6 +37,7 @@ class SiteLevel:
         self._hash = None
         self._subm = None
         self._down = None
+        self._parity = None
 
     @property
     def hash(self):
@@ -49,6 +50,16 @@ class SiteLevel:
         if self._subm is None:
             self._subm = ops.rulebook_subm(self.hash)
         return self._subm
+
+    def parity_order(self):
+        """Rows grouped by the parity of (z, y, x), original order kept inside a group (int32 [M]).  Under a
+        k=3, s=2, p=1 conv the kernel offsets that can reach a fine site are fixed by its parity (1, 2, 4 or 8 of
+        the 27), so tiles of same-parity rows of the inverse table skip the other offsets wholesale."""
+        if self._parity is None:
+            c = self.coords
+            key = (c[:, 1] & 1) * 4 + (c[:, 2] & 1) * 2 + (c[:, 3] & 1)
+            self._parity = torch.sort(key, stable=True)[1].to(torch.int32)
+        return self._parity
 
     def down(self):
         """(coarse SiteLevel, nbr_fwd [27, M_coarse], nbr_inv [27, M]) of SparseConv3d(k=3, s=2, p=1)."""
@@ -114,12 +125,12 @@ class _Conv3x3x3(SparseModule):
                 self._packed = (key, ops.pack_weight(w, ops.PACK_FWD))
         return self._packed[1]
 
-    def _apply_tables(self, feats, nbr, nbr_t, t_flags):
+    def _apply_tables(self, feats, nbr, nbr_t, t_flags, order=None, order_t=None):
         if self._pad_in:
             feats = torch.nn.functional.pad(feats, (0, self._pad_in))
             weight = torch.nn.functional.pad(self.weight, (0, self._pad_in))
-            return ops.sparse_conv(feats, weight, self.bias, nbr, nbr_t, t_flags, None)
-        return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight())
+            return ops.sparse_conv(feats, weight, self.bias, nbr, nbr_t, t_flags, None, order, order_t)
+        return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight(), order, order_t)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size=3, stride={self.stride}, " \
@@ -139,7 +150,7 @@ class SparseConv3d(_Conv3x3x3):
         coarse, fwd, inv = x.level.down()
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = x.level
-        return x.on_level(self._apply_tables(x.features, fwd, inv, ops.PACK_T), coarse)
+        return x.on_level(self._apply_tables(x.features, fwd, inv, ops.PACK_T, None, x.level.parity_order()), coarse)
 
 
 class SparseInverseConv3d(_Conv3x3x3):
@@ -153,7 +164,7 @@ class SparseInverseConv3d(_Conv3x3x3):
         coarse, fwd, inv = fine.down()
         if coarse is not x.level:
             raise RuntimeError("SparseInverseConv3d input does not live on the paired strided conv's output sites")
-        return x.on_level(self._apply_tables(x.features, inv, fwd, ops.PACK_T), fine)
+        return x.on_level(self._apply_tables(x.features, inv, fwd, ops.PACK_T, fine.parity_order(), None), fine)
 
 
 class SparseSequential(SparseModule):
