@@ -61,4 +61,4 @@ def test_host_only_entry_points():
     assert _lib.query("seg3d_coord_hash_bytes", 1000) == 2048 * 12
     # argument validation happens before anything is enqueued: a null call is rejected, not launched
     assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 0, None, 48, 48, None, None, None) == _lib.EINVAL
-    assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 4, None, 50, 48, None, None) == _lib.EINVAL
+    assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 4, None, 50, 48, None, None, None) == _lib.EINVAL
