@@ -102,6 +102,9 @@ def load():
         raise Seg3dError(
             f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
             "Build it with `python __graft_entry__.py`.")
+    # torch first: its bundled HIP runtime must be the one this library binds to (the streams and device pointers
+    # handed over come from it); loading the library before torch would pull in a second runtime from /opt/rocm
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
