@@ -361,6 +361,15 @@ int seg3d_knn_grid_query(const seg3d_knn_level* levels, int32_t n_levels, const 
                          int32_t* idx, float* dist2, void* stream);
 
 /*
+ * SURVEY 8(f) rank 2  WaymoDataset.prepare_voxel_labels (seg3d/datasets/waymo_dataset.py:213-246): label of a voxel =
+ * most frequent label (uint8, 0..255, the ignore label counted like any other) among its points, ties to the smallest
+ * label, ignore_index for voxels without a point.  order / offsets: the point->voxel CSR of seg3d_group_index
+ * (points with id -1 -- dropped or history-sweep points -- are in no segment).
+ */
+int seg3d_voxel_majority_labels(const uint8_t* point_labels, const int32_t* order, const int32_t* offsets,
+                                int64_t n_voxels, int32_t ignore_index, uint8_t* voxel_labels, void* stream);
+
+/*
  * SURVEY 8(f)  cross-entropy term of the training loss (tools/train.py: nn.CrossEntropyLoss(ignore_index=...), mean
  * over the counted rows) on logits [n, c] with int64 labels; rows whose label is ignore_index (or outside [0, c))
  * contribute nothing.  forward: lse [n] kept for backward, stats = {mean loss, count}; backward: dlogits =

@@ -128,9 +128,44 @@ int launch_reduce(const float* x, int c, const int32_t* order, const int32_t* of
     return SEG3D_OK;
 }
 
+// prepare_voxel_labels (seg3d/datasets/waymo_dataset.py:213-246): per voxel the most frequent
+// label of its (current-sweep) points, ties to the smallest label (np.argmax of a 256-bin counter), voxels without a
+// point keep ignore_index.  One thread per voxel over the point->voxel CSR; a voxel holds ~1.6 points on average, so
+// counting every point's label against the others (n^2) beats a 256-bin histogram.
+__global__ __launch_bounds__(kThreads) void voxel_majority_kernel(const uint8_t* __restrict__ labels,
+                                                                  const int32_t* __restrict__ order,
+                                                                  const int32_t* __restrict__ offsets, int64_t n_seg,
+                                                                  int ignore_index, uint8_t* __restrict__ out) {
+    const int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (v >= n_seg) return;
+    const int b = offsets[v], e = offsets[v + 1];
+    int best = ignore_index, best_cnt = 0;
+    for (int i = b; i < e; ++i) {
+        const int li = labels[order[i]];
+        int cnt = 0;
+        for (int j = b; j < e; ++j) cnt += labels[order[j]] == li;
+        if (cnt > best_cnt || (cnt == best_cnt && li < best)) {
+            best = li;
+            best_cnt = cnt;
+        }
+    }
+    out[v] = (uint8_t)best;
+}
+
 }  // namespace
 
 extern "C" {
+
+int seg3d_voxel_majority_labels(const uint8_t* point_labels, const int32_t* order, const int32_t* offsets, int64_t n_voxels,
+                                int32_t ignore_index, uint8_t* voxel_labels, void* stream) {
+    if (n_voxels < 0 || ignore_index < 0 || ignore_index > 255) return SEG3D_EINVAL;
+    if (n_voxels == 0) return SEG3D_OK;
+    if (!point_labels || !order || !offsets || !voxel_labels) return SEG3D_EINVAL;
+    hipLaunchKernelGGL(voxel_majority_kernel, dim3((unsigned)ceil_div64(n_voxels, kThreads)), dim3(kThreads), 0,
+                       as_stream(stream), point_labels, order, offsets, n_voxels, (int)ignore_index, voxel_labels);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
 
 int seg3d_segment_reduce_fwd(const float* x, int32_t c, const int32_t* order, const int32_t* offsets, int64_t n_seg,
                              int32_t mode, float* out, int32_t* argmax, void* stream) {

@@ -945,6 +945,24 @@ def knn_query(nsample, xyz, new_xyz, offset, new_offset):
     return idx, torch.sqrt(d2)
 
 
+# ------------------------------------------------------------------------------------------ labels
+def prepare_voxel_labels(point_voxel_ids, point_labels, n_voxels, ignore_index=255, cur_point_indices=None):
+    """``WaymoDataset.prepare_voxel_labels`` (waymo_dataset.py:213-246) on the device: uint8 [n_voxels], the most
+    frequent label among each voxel's (current-sweep) points, ties to the smallest label, ``ignore_index`` where a
+    voxel has no such point.  point_voxel_ids: int [N] (-1 = dropped point); point_labels: integer [N_cur] in 0..255;
+    cur_point_indices: rows of the current sweep (multi-sweep configs), or None."""
+    _need_gpu(point_voxel_ids, point_labels)
+    ids = point_voxel_ids if cur_point_indices is None else point_voxel_ids[cur_point_indices]
+    if ids.shape[0] != point_labels.shape[0]:
+        raise _lib.Seg3dError("prepare_voxel_labels: one label per (current-sweep) point expected")
+    seg = SegmentIndex(ids, n_voxels)
+    lab = point_labels.to(torch.uint8).contiguous()
+    out = torch.empty((int(n_voxels),), dtype=torch.uint8, device=lab.device)
+    _lib.call("seg3d_voxel_majority_labels", _ptr(lab), _ptr(seg.order), _ptr(seg.offsets), int(n_voxels), int(ignore_index),
+              _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f): loss
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod

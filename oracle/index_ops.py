@@ -126,3 +126,19 @@ def rulebook_strided(coords_in, shape_in, coords_out, shape_out):
     )
     assert rc == 0
     return fwd, inv
+
+
+def prepare_voxel_labels(point_voxel_ids, point_labels, n_voxels, ignore_index=255):
+    """seg3d/datasets/waymo_dataset.py:213-246 restated with numpy: per voxel np.argmax of a 256-bin counter over its
+    points' labels (first maximum = smallest label on ties), ignore_index for voxels without a point."""
+    import numpy as np
+    ids = np.asarray(point_voxel_ids).astype(np.int64)
+    lab = np.asarray(point_labels).astype(np.int64)
+    out = np.full((int(n_voxels),), ignore_index, dtype=np.uint8)
+    ok = ids != -1
+    if ok.any():
+        counter = np.zeros((int(n_voxels), 256), dtype=np.int32)
+        np.add.at(counter, (ids[ok], lab[ok]), 1)
+        seen = counter.sum(1) > 0
+        out[seen] = counter[seen].argmax(1).astype(np.uint8)
+    return out

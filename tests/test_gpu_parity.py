@@ -502,3 +502,23 @@ def test_knn_grid_matches_brute_force(dev, monkeypatch, k):
     monkeypatch.setattr(ops, "KNN_GRID_MIN_POINTS", 1)
     i3, d3 = ops.knn_query(k, xyz, qs, off, qoff)
     assert torch.equal(i2, i3) and torch.equal(d2, d3)
+
+
+def test_prepare_voxel_labels_matches_reference_rule(dev):
+    """Majority vote per voxel with np.argmax tie rule (waymo_dataset.py:213-246), incl. dropped points, empty voxels,
+    the ignore label competing like any other, and the current-sweep subset of the multi-sweep configs."""
+    from oracle import index_ops
+    from openseg3d_amd import ops
+    rs = np.random.RandomState(5)
+    n, m = 50000, 9000
+    ids = rs.randint(-1, m - 500, n).astype(np.int64)  # the last 500 voxels stay empty
+    ids[:2000] = rs.randint(0, 40, 2000)               # crowded voxels: ties and long runs
+    lab = rs.choice(np.array([0, 1, 2, 3, 21, 255]), n).astype(np.int64)
+    want = index_ops.prepare_voxel_labels(ids, lab, m)
+    got = ops.prepare_voxel_labels(torch.from_numpy(ids).to(dev), torch.from_numpy(lab).to(dev), m)
+    assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), want)
+    cur = np.sort(rs.choice(n, n // 3, replace=False))
+    want = index_ops.prepare_voxel_labels(ids[cur], lab[cur], m)
+    got = ops.prepare_voxel_labels(torch.from_numpy(ids).to(dev), torch.from_numpy(lab[cur]).to(dev), m,
+                                   cur_point_indices=torch.from_numpy(cur).to(dev))
+    assert np.array_equal(got.cpu().numpy(), want)

@@ -137,3 +137,22 @@ def test_knn_oracle_semantics():
     t = torch.tensor([[0., 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0]])
     o = torch.tensor([4], dtype=torch.int32)
     assert knn_query(4, t, t, o, o)[0][0].tolist() == [0, 1, 2, 3]
+
+
+def test_oracle_prepare_voxel_labels_follows_the_reference_loop():
+    """oracle.index_ops.prepare_voxel_labels against a literal transcription of the counting rule of
+    seg3d/datasets/waymo_dataset.py:213-246 (uint16 256-bin counter per voxel, np.argmax) on a small case."""
+    import numpy as np
+    from oracle import index_ops
+    rs = np.random.RandomState(1)
+    n, m = 400, 60
+    ids = rs.randint(-1, m - 5, n)
+    lab = rs.choice(np.array([0, 3, 7, 21, 255]), n)
+    counters = {}
+    for i in range(n):
+        if ids[i] != -1:
+            counters.setdefault(int(ids[i]), np.zeros((256,), dtype=np.uint16))[lab[i]] += 1
+    want = np.ones(m, dtype=np.uint8) * 255
+    for v, c in counters.items():
+        want[v] = np.argmax(c)
+    assert np.array_equal(index_ops.prepare_voxel_labels(ids, lab, m), want)
