@@ -963,6 +963,27 @@ def prepare_voxel_labels(point_voxel_ids, point_labels, n_voxels, ignore_index=2
     return out
 
 
+def get_voxel_centers(voxel_coords, downsample_scale, voxel_size, point_cloud_range):
+    """``seg3d.utils.pointops_utils.get_voxel_centers`` (pointops_utils.py:14-22): (z, y, x) cells -> xyz centres."""
+    centers = voxel_coords[:, [2, 1, 0]].float()
+    vs = torch.tensor(voxel_size, device=centers.device).float() * downsample_scale
+    lo = torch.tensor(point_cloud_range[0:3], device=centers.device).float()
+    return (centers + 0.5) * vs + lo
+
+
+def aux_voxel_labels(voxel_coords, aux_voxel_coords, voxel_labels, batch_size, voxel_size, point_cloud_range,
+                     aux_scale=8.0):
+    """Ground truth of the auxiliary (stride-8) voxel head as tools/train.py:86-104 builds it: every coarse voxel takes
+    the label of the nearest fine voxel centre of its sample (knn_query with k = 1).  coords: [M, 4] (b, z, y, x).
+    The per-sample counts come from one bincount instead of a Python loop of host syncs."""
+    centers = get_voxel_centers(voxel_coords[:, 1:], 1.0, voxel_size, point_cloud_range).contiguous()
+    aux_centers = get_voxel_centers(aux_voxel_coords[:, 1:], aux_scale, voxel_size, point_cloud_range).contiguous()
+    off = torch.cumsum(torch.bincount(voxel_coords[:, 0].long(), minlength=batch_size), 0).int()
+    aux_off = torch.cumsum(torch.bincount(aux_voxel_coords[:, 0].long(), minlength=batch_size), 0).int()
+    idx, _ = knn_query(1, centers, aux_centers, off, aux_off)
+    return voxel_labels[idx.reshape(-1).long()]
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f): loss
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod

@@ -522,3 +522,23 @@ def test_prepare_voxel_labels_matches_reference_rule(dev):
     got = ops.prepare_voxel_labels(torch.from_numpy(ids).to(dev), torch.from_numpy(lab[cur]).to(dev), m,
                                    cur_point_indices=torch.from_numpy(cur).to(dev))
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_aux_voxel_labels_take_the_nearest_fine_voxel(dev):
+    """tools/train.py:86-104: label of a stride-8 voxel = label of the nearest fine voxel centre of the same sample."""
+    from openseg3d_amd import ops
+    rs = np.random.RandomState(9)
+    vs, rng = [0.1, 0.1, 0.1], [-72.0, -72.0, -2.0, 72.0, 72.0, 4.4]
+    fine = np.unique(np.concatenate([np.concatenate([np.full((6000, 1), b), rs.randint(0, 64, (6000, 1)),
+                                                     rs.randint(0, 1440, (6000, 2))], 1) for b in (0, 1)]), axis=0)
+    coarse = np.unique(np.concatenate([fine[:, :1], fine[:, 1:] // 8], 1), axis=0)
+    labels = rs.randint(0, 22, fine.shape[0])
+    f, c = torch.from_numpy(fine).int().to(dev), torch.from_numpy(coarse).int().to(dev)
+    got = ops.aux_voxel_labels(f, c, torch.from_numpy(labels).to(dev), 2, vs, rng).cpu().numpy()
+    fc = (fine[:, [3, 2, 1]].astype(np.float32) + 0.5) * np.float32(0.1) + np.array(rng[:3], np.float32)
+    cc = (coarse[:, [3, 2, 1]].astype(np.float32) + 0.5) * np.float32(0.8) + np.array(rng[:3], np.float32)
+    for i in rs.choice(coarse.shape[0], 200, replace=False):
+        same = np.nonzero(fine[:, 0] == coarse[i, 0])[0]
+        d = fc[same] - cc[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert got[i] == labels[same[np.argmin(d2)]] or np.sum(d2 == d2.min()) > 1
