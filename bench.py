@@ -43,6 +43,8 @@ def parse():
                     help="one_sweep = BASELINE configs[1] (the headline); cylinder = configs[2] geometry "
                          "(waymo_one_sweep_cylinder.yaml, use --batch 4); multi_sweeps = configs[3] "
                          "(waymo_multi_sweeps.yaml + image features, 3 sweeps, use --batch 2)")
+    ap.add_argument("--segmentor", choices=["segformer", "spnet"], default="segformer",
+                    help="MODEL.SEGMENTOR (builder.py:8-23); segformer is the headline, spnet = SparseUnet + OCR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU-baseline sample (0 = whole scene)")
     return ap.parse_args()
@@ -144,7 +146,7 @@ def conv_roofline(model, batch, dev):
             p = json.load(f)
         if abs(p.get("algorithmic_bytes_per_launch", 0) - tot_bytes / n) <= 0.01 * tot_bytes / n:
             traffic = p["traffic_bytes_per_launch"]
-    return {"bound": "hbm", "kernel": "spconv_split_kernel (all 20 sparse-conv launches of one forward)",
+    return {"bound": "hbm", "kernel": f"spconv_split_kernel (all {len(records)} sparse-conv launches of one forward)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches": len(records),
             "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
@@ -169,10 +171,10 @@ def cpu_baseline(scene_np, cfg, ds, model, n_points):
             "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS}
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     with torch.no_grad():
-        omodel.segformer_forward(batch, sd, ocfg)
+        (omodel.spnet_forward if cfg.MODEL.SEGMENTOR == "spnet" else omodel.segformer_forward)(batch, sd, ocfg)
     dt = time.time() - t0
     return {"value": round(pts.shape[0] / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": f"1 forward (voxelize + Segformer eval) of {pts.shape[0]} points of scene seed 0, "
+            "sample": f"1 forward (voxelize + {cfg.MODEL.SEGMENTOR} eval) of {pts.shape[0]} points of scene seed 0, "
                       f"{coords.shape[0]} voxels, {dt:.1f} s, torch.set_num_threads({cores})"}
 
 
@@ -191,6 +193,7 @@ def main():
     elif args.workload == "multi_sweeps":  # configs/waymo_multi_sweeps.yaml:1-4 + USE_IMAGE_FEATURE
         cfg.DATASET.USE_MULTI_SWEEPS = True
         cfg.DATASET.USE_IMAGE_FEATURE = True
+    cfg.MODEL.SEGMENTOR = args.segmentor
     ds = config.DatasetSpec(cfg)
     torch.manual_seed(0)
     model = segformer.build_segmentor(cfg, ds).to(dev)
@@ -278,12 +281,12 @@ def main():
                                     }[args.workload] + ": synthetic 64-beam scene, "
                                    f"{pts_per_step[0]} pts/step/GPU, voxel {ds.voxel_size}, grid {ds.grid_size.tolist()}, "
                                    f"{'forward-only eval' if not train else 'fwd+loss+bwd+SGD step'}",
-                       "mode": args.mode, "scenes_per_step_per_gpu": args.batch,
+                       "mode": args.mode, "segmentor": args.segmentor, "scenes_per_step_per_gpu": args.batch,
                        "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}"},
             "fwd_only": {"value": round(n_pts_f / dt_f, 1), "unit": "points/s",
                          "ms_per_step": round(dt_f / args.steps * 1e3, 3)},
             "roofline": roof,
-            "attention_roofline": ATTENTION_REPORT,
+            "attention_roofline": ATTENTION_REPORT if args.segmentor == "segformer" else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scenes_np[0], cfg, ds, model, args.cpu_points)

@@ -352,9 +352,12 @@ class Segformer(nn.Module):
 
 
 def build_segmentor(cfg, dataset):
-    """seg3d/models/builder.py:8-23 for the segformer branch."""
+    """seg3d/models/builder.py:8-23: 'segformer' (the default every shipped config uses) or 'spnet'."""
+    if cfg.MODEL.SEGMENTOR == "spnet":
+        from .spnet import SPNet
+        return SPNet(dataset=dataset)
     if cfg.MODEL.SEGMENTOR != "segformer":
-        raise NotImplementedError("only MODEL.SEGMENTOR='segformer' (the default every shipped config uses)")
+        raise NotImplementedError(f"MODEL.SEGMENTOR={cfg.MODEL.SEGMENTOR!r}: the reference builds 'segformer' or 'spnet'")
     batching_info = [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO]
     return Segformer(dataset=dataset, batching_info=batching_info, window_shape=cfg.MODEL.WINDOW_SHAPE,
                      depths=cfg.MODEL.DEPTHS, drop_path_rate=cfg.MODEL.DROP_PATH_RATE)

@@ -38,6 +38,22 @@ class SiteLevel:
         self._subm = None
         self._down = None
         self._parity = None
+        self._offsets = False
+
+    def sample_offsets(self):
+        """Cumulative row count per sample as python ints when every sample's rows are contiguous and in sample
+        order (always true for collated voxel lists and for the sorted coarse levels), else None.  One host sync
+        per level for batch_size > 1, none for a single sample."""
+        if self._offsets is False:
+            m = self.coords.shape[0]
+            if self.batch_size == 1:
+                self._offsets = [m]
+            else:
+                b = self.coords[:, 0]
+                cnt = torch.bincount(b, minlength=self.batch_size)
+                ordered = bool((b[1:] >= b[:-1]).all()) if m > 1 else True
+                self._offsets = torch.cumsum(cnt, 0).tolist() if ordered and cnt.numel() == self.batch_size else None
+        return self._offsets
 
     @property
     def hash(self):

@@ -1,4 +1,4 @@
-"""Oracle restatement of Segformer.forward in eval mode -- TEST INFRASTRUCTURE ONLY.
+"""Oracle restatement of Segformer.forward and SPNet.forward in eval mode -- TEST INFRASTRUCTURE ONLY.
 
 Functional torch-CPU forward driven by a state_dict keyed exactly like the
 reference module tree (SURVEY.md section 8b "state-dict"):
@@ -42,12 +42,22 @@ def _conv_module(x, nbr, p, pre):
     return F.relu(_bn(y, p, pre + "1.", BN_EPS_SPARSE))
 
 
-def _basic_block(x, nbr, p, pre):
-    """SparseBasicBlock.forward (no SE/SA in PointTransformer), pointtransformer.py:47-66."""
+def _flatten_se(x, bidx, p, pre):
+    """FlattenSELayer.forward, se_layer.py:24-28: per-sample mean -> fc -> sigmoid gate."""
+    g = sc.scatter(x, bidx, reduce="mean")
+    g = torch.sigmoid(F.linear(F.relu(F.linear(g, p[pre + "fc.0.weight"])), p[pre + "fc.2.weight"]))
+    return x * g[bidx]
+
+
+def _basic_block(x, nbr, p, pre, se_batch=None):
+    """SparseBasicBlock.forward, pointtransformer.py:47-66 (no SE/SA) and spconv_unet.py:46-66
+    (``se_batch`` = the batch column of the sites when the block was built with_se=True)."""
     y = sc.apply_rulebook(x, nbr, p[pre + "conv1.weight"], p[pre + "conv1.bias"])
     y = F.relu(_bn(y, p, pre + "bn1.", BN_EPS_SPARSE))
     y = sc.apply_rulebook(y, nbr, p[pre + "conv2.weight"], p[pre + "conv2.bias"])
     y = _bn(y, p, pre + "bn2.", BN_EPS_SPARSE)
+    if se_batch is not None:
+        y = _flatten_se(y, se_batch, p, pre + "se.")
     return F.relu(y + x)
 
 
@@ -58,6 +68,42 @@ def _up_block(x_bottom, x_lateral, nbr_subm, nbr_out, p, pre):
     m = _conv_module(cat, nbr_subm, p, pre + "bottleneck.")
     red = cat.view(cat.shape[0], m.shape[1], -1).sum(dim=2)
     return _conv_module(m + red, nbr_out, p, pre + "out.")
+
+
+def _fusion_head(batch, p, cfg, pf, x, cur, cur_points):
+    """Voxel->point gather, optional DeepFusion, fusion MLP, SE and classifier: segformer.py:112-138, identical in
+    spnet.py:113-140."""
+    ids = batch["point_voxel_ids"]
+    multi = cur is not None
+    pv = sc.voxel_to_point(x, ids[cur] if multi else ids)
+    f = torch.cat([pf, pv], dim=1)
+    if cfg.get("use_image_feature", False):  # DeepFusionBlock.forward, deep_fusion.py:26-45 (eval: no dropout)
+        from .knn import knn_query
+        img = batch["point_image_features"]
+        df = "deep_fusion."
+        q = F.linear(f, p[df + "q_embedding.weight"], p[df + "q_embedding.bias"])
+        kk = F.linear(img, p[df + "k_embedding.weight"], p[df + "k_embedding.bias"])
+        vv = F.linear(img, p[df + "v_embedding.weight"], p[df + "v_embedding.bias"])
+        off = batch["point_id_offset"].int()
+        nn_ids, _ = knn_query(16, cur_points.contiguous(), cur_points.contiguous(), off, off)
+        nn_ids = nn_ids.long()
+        w = torch.einsum("nc,nkc->nk", q, kk[nn_ids]) / np.sqrt(q.shape[-1])
+        w[(img.sum(dim=1) == 0)[nn_ids]] = float("-inf")
+        w = torch.nan_to_num(torch.softmax(w, dim=-1))
+        o = torch.einsum("nk,nkc->nc", w, vv[nn_ids])
+        f = torch.cat([f, F.linear(o, p[df + "c_proj.weight"], p[df + "c_proj.bias"])], dim=1)
+    fe = "fusion_encoder."
+    f = F.relu(_bn(F.linear(f, p[fe + "0.weight"]), p, fe + "1.", 1e-5))
+    f = F.relu(_bn(F.linear(f, p[fe + "3.weight"]), p, fe + "4.", 1e-5))
+    f = F.relu(_bn(F.linear(f, p[fe + "6.weight"]), p, fe + "7.", 1e-5))
+
+    bidx = (batch["points"][:, 0][cur] if multi else batch["points"][:, 0]).long()
+    f = f + _flatten_se(f, bidx, p, "se.")
+
+    h = F.relu(_bn(F.linear(f, p["classifier.0.weight"]), p, "classifier.1.", 1e-5))
+    point_out = F.linear(h, p["classifier.4.weight"])
+
+    return point_out
 
 
 def segformer_forward(batch, params, cfg):
@@ -117,38 +163,85 @@ def segformer_forward(batch, params, cfg):
     x = _up_block(x, feats[0], lvl[0].subm(), lvl[0].subm(), p, pre + "up1.")
     voxel_out = F.linear(x, p[pre + "voxel_classifier.0.weight"])
 
-    pv = sc.voxel_to_point(x, ids[cur] if multi else ids)
-    f = torch.cat([pf, pv], dim=1)
-    if cfg.get("use_image_feature", False):  # DeepFusionBlock.forward, deep_fusion.py:26-45 (eval: no dropout)
-        from .knn import knn_query
-        img = batch["point_image_features"]
-        df = "deep_fusion."
-        q = F.linear(f, p[df + "q_embedding.weight"], p[df + "q_embedding.bias"])
-        kk = F.linear(img, p[df + "k_embedding.weight"], p[df + "k_embedding.bias"])
-        vv = F.linear(img, p[df + "v_embedding.weight"], p[df + "v_embedding.bias"])
-        off = batch["point_id_offset"].int()
-        nn_ids, _ = knn_query(16, cur_points.contiguous(), cur_points.contiguous(), off, off)
-        nn_ids = nn_ids.long()
-        w = torch.einsum("nc,nkc->nk", q, kk[nn_ids]) / np.sqrt(q.shape[-1])
-        w[(img.sum(dim=1) == 0)[nn_ids]] = float("-inf")
-        w = torch.nan_to_num(torch.softmax(w, dim=-1))
-        o = torch.einsum("nk,nkc->nc", w, vv[nn_ids])
-        f = torch.cat([f, F.linear(o, p[df + "c_proj.weight"], p[df + "c_proj.bias"])], dim=1)
-    fe = "fusion_encoder."
-    f = F.relu(_bn(F.linear(f, p[fe + "0.weight"]), p, fe + "1.", 1e-5))
-    f = F.relu(_bn(F.linear(f, p[fe + "3.weight"]), p, fe + "4.", 1e-5))
-    f = F.relu(_bn(F.linear(f, p[fe + "6.weight"]), p, fe + "7.", 1e-5))
-
-    bidx = (batch["points"][:, 0][cur] if multi else batch["points"][:, 0]).long()
-    g = sc.scatter(f, bidx, reduce="mean")  # FlattenSELayer, se_layer.py:24-28
-    g = torch.sigmoid(F.linear(F.relu(F.linear(g, p["se.fc.0.weight"])), p["se.fc.2.weight"]))
-    f = f + f * g[bidx]
-
-    h = F.relu(_bn(F.linear(f, p["classifier.0.weight"]), p, "classifier.1.", 1e-5))
-    point_out = F.linear(h, p["classifier.4.weight"])
+    point_out = _fusion_head(batch, p, cfg, pf, x, cur if multi else None, cur_points)
 
     res = OrderedDict()
     res["point_out"] = point_out
+    res["voxel_out"] = voxel_out
+    res["aux_voxel_out"] = aux
+    res["voxel_coords"] = torch.from_numpy(lvl[0].coords)
+    res["aux_voxel_coords"] = torch.from_numpy(lvl[3].coords)
+    res["_levels"] = lvl
+    res["_stage_feats"] = feats
+    res["_voxel_in"] = vox
+    return res
+
+
+def _ocr(x, sites, aux, batch_size, p, pre):
+    """OCRLayer.forward in eval mode, seg3d/models/layers/ocr.py:104-116 (SpatialGatherModule :19-36,
+    ObjectAttentionBlock :69-82)."""
+    f = F.relu(_bn(sc.apply_rulebook(x, sites.subm(), p[pre + "transform_input.0.weight"]), p,
+                   pre + "transform_input.1.", 1e-5))
+    bidx = torch.from_numpy(sites.coords[:, 0]).long()
+    oc = pre + "object_context_block."
+
+    def proj(t, name):
+        return F.relu(_bn(F.linear(t, p[oc + name + ".0.weight"]), p, oc + name + ".1.", 1e-5))
+
+    key_channels = p[oc + "query_project.0.weight"].shape[0]
+    out = torch.zeros_like(f)
+    for i in range(batch_size):
+        sel = bidx == i
+        fi = f[sel]
+        prob = F.softmax(aux[sel].t(), dim=1)  # scale = 1, ocr.py:86
+        proxy = prob @ fi  # [classes, C]
+        sim = F.softmax((key_channels ** -0.5) * (proj(fi, "query_project") @ proj(proxy, "key_project").t()), dim=-1)
+        out[sel] = proj(sim @ proj(proxy, "value_project"), "bottleneck")
+    cat = torch.cat([out, f], dim=1)
+    return F.relu(_bn(F.linear(cat, p[pre + "bottleneck.0.weight"]), p, pre + "bottleneck.1.", 1e-5))
+
+
+def spnet_forward(batch, params, cfg):
+    """SPNet.forward in eval mode: seg3d/models/segmentors/spnet.py:94-148 over
+    SparseUnet.forward, seg3d/models/backbones/spconv_unet.py:186-233.  Same batch / cfg / result contract as
+    segformer_forward (cfg needs grid_size only, plus the multi-sweep / image switches)."""
+    p = params
+    points = batch["points"][:, 1:]
+    ids = batch["point_voxel_ids"]
+    multi = bool(cfg.get("use_multi_sweeps", False))
+    cur = points[:, 3] == 0 if multi else None  # spnet.py:97
+    cur_points = points[cur] if multi else points
+    pf = _point_encoder(cur_points, p)
+    ok = ids != -1
+    vox = sc.scatter(points[ok], ids[ok], reduce="mean") if multi else sc.scatter(pf[ok], ids[ok], reduce="max")
+
+    coords = batch["voxel_coords"].int().numpy()
+    lvl = [sc.Sites(coords, np.asarray(cfg["grid_size"])[::-1])]
+    pre = "voxel_encoder."
+    x = _conv_module(vox, lvl[0].subm(), p, pre + "conv_input.")
+    for j in range(2):
+        x = _basic_block(x, lvl[0].subm(), p, f"{pre}conv1.{j}.")
+    feats = [x]
+    for k in range(1, 4):  # conv2..conv4: strided conv + 3 blocks, SE on the last block of conv3 / conv4
+        coarse, fwd, _ = lvl[k - 1].down()
+        lvl.append(coarse)
+        x = _conv_module(feats[-1], fwd, p, f"{pre}conv{k + 1}.0.")
+        bcol = torch.from_numpy(coarse.coords[:, 0]).long()
+        for j in (1, 2, 3):
+            x = _basic_block(x, coarse.subm(), p, f"{pre}conv{k + 1}.{j}.", se_batch=bcol if (k >= 2 and j == 3) else None)
+        feats.append(x)
+
+    aux = F.linear(feats[3], p[pre + "aux_voxel_classifier.0.weight"])
+    x4 = _ocr(feats[3], lvl[3], aux, int(batch["batch_size"]), p, pre + "ocr.")
+
+    x = _up_block(x4, x4, lvl[3].subm(), lvl[2].down()[2], p, pre + "up4.")
+    x = _up_block(x, feats[2], lvl[2].subm(), lvl[1].down()[2], p, pre + "up3.")
+    x = _up_block(x, feats[1], lvl[1].subm(), lvl[0].down()[2], p, pre + "up2.")
+    x = _up_block(x, feats[0], lvl[0].subm(), lvl[0].subm(), p, pre + "up1.")
+    voxel_out = F.linear(x, p[pre + "voxel_classifier.0.weight"])
+
+    res = OrderedDict()
+    res["point_out"] = _fusion_head(batch, p, cfg, pf, x, cur, cur_points)
     res["voxel_out"] = voxel_out
     res["aux_voxel_out"] = aux
     res["voxel_coords"] = torch.from_numpy(lvl[0].coords)

@@ -469,6 +469,38 @@ def test_segformer_multi_sweep_fusion_matches_reference_model(dev, golden_dir):
     assert not [k for k, p in model.named_parameters() if p.grad is None]
 
 
+@pytest.mark.parametrize("tag", ["cart", "ms"])
+def test_spnet_logits_match_reference_model(dev, golden_dir, tag):
+    """MODEL.SEGMENTOR='spnet' (SparseUnet + OCR, builder.py:17-18): logits within 1e-3 of the reference model code,
+    voxel indices bit-exact; 3-sample batch with out-of-range points (cart) and multi-sweep + image fusion (ms)."""
+    from oracle import params
+    from openseg3d_amd import config, segformer
+    d = np.load(os.path.join(golden_dir, f"spnet_{tag}.npz"))
+    cfg = config.default_cfg()
+    cfg.MODEL.SEGMENTOR = "spnet"
+    cfg.DATASET.USE_MULTI_SWEEPS = cfg.DATASET.USE_IMAGE_FEATURE = tag == "ms"
+    model = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    params.fill_by_name(model, seed=3)
+    model = model.to(dev).eval()
+    names = ["points", "voxel_coords", "point_voxel_ids", "point_id_offset"] + (["point_image_features"] if tag == "ms" else [])
+    batch = {k: torch.from_numpy(d[k]).to(dev) for k in names}
+    batch["batch_size"] = int(d["batch_size"])
+    with torch.no_grad():
+        res = model(batch)
+    assert np.array_equal(_np(res["aux_voxel_coords"]), d["aux_voxel_coords"])
+    assert np.array_equal(_np(res["voxel_coords"]), d["voxel_coords"].astype(np.int32))
+    for k in ("point_out", "voxel_out", "aux_voxel_out"):
+        err = float(np.abs(_np(res[k]) - d[k]).max())
+        assert err < 1e-3, (k, err)
+    # and it trains: every parameter (OCR included) receives a finite gradient
+    model.train()
+    batch = {k: torch.from_numpy(d[k]).to(dev) for k in names}
+    batch["batch_size"] = int(d["batch_size"])
+    res = model(batch)
+    (res["point_out"].square().mean() + res["voxel_out"].mean() + res["aux_voxel_out"].mean()).backward()
+    assert not [k for k, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+
+
 @pytest.mark.parametrize("k", [1, 16])
 def test_knn_grid_matches_brute_force(dev, monkeypatch, k):
     """The grid-accelerated search must return exactly what the brute-force kernel returns (indices and distances),

@@ -80,10 +80,25 @@ def test_multi_sweep_image_fusion_state_dict_contract(golden_dir):
     assert sd["point_transformer.conv_input.0.weight"].shape[-1] == 6  # raw point rows feed the voxel encoder
 
 
-def test_unsupported_configs_are_refused():
+@pytest.mark.parametrize("tag", ["cart", "ms"])
+def test_spnet_state_dict_contract(golden_dir, tag):
+    """MODEL.SEGMENTOR='spnet' (builder.py:17-18): same keys and shapes as the reference SPNet/SparseUnet/OCRLayer."""
     from openseg3d_amd import config, segformer
     cfg = config.default_cfg()
     cfg.MODEL.SEGMENTOR = "spnet"
+    cfg.DATASET.USE_MULTI_SWEEPS = cfg.DATASET.USE_IMAGE_FEATURE = tag == "ms"
+    model = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    keys = json.load(open(os.path.join(golden_dir, f"spnet_{tag}_keys.json")))
+    sd = model.state_dict()
+    assert set(sd) == set(keys)
+    assert all(list(sd[k].shape) == list(keys[k]) for k in keys)
+    assert list(sd) == list(keys)  # registration order too: optimizers index parameters by position
+
+
+def test_unsupported_configs_are_refused():
+    from openseg3d_amd import config, segformer
+    cfg = config.default_cfg()
+    cfg.MODEL.SEGMENTOR = "minkunet"
     with pytest.raises(NotImplementedError):
         segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
 

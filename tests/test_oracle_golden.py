@@ -124,6 +124,25 @@ def test_segformer_multi_sweep_fusion_matches_reference_model_code(golden_dir):
         assert float((res[k] - torch.from_numpy(d[k])).abs().max()) <= 1e-4, k
 
 
+@pytest.mark.parametrize("tag", ["cart", "ms"])
+def test_spnet_matches_reference_model_code(golden_dir, tag):
+    """Oracle SPNet forward (SparseUnet + OCR) vs the reference's spnet.py / spconv_unet.py / ocr.py run on the
+    oracle's spconv stand-ins (make_golden.gen_spnet); 3 samples in the cartesian case, out-of-range points."""
+    keys = json.load(open(os.path.join(golden_dir, f"spnet_{tag}_keys.json")))
+    d = np.load(os.path.join(golden_dir, f"spnet_{tag}.npz"))
+    p = params.state_dict_for(keys, 3)
+    names = ["points", "voxel_coords", "point_voxel_ids", "point_id_offset"] + (["point_image_features"] if tag == "ms" else [])
+    batch = {k: torch.from_numpy(d[k]) for k in names}
+    batch["batch_size"] = int(d["batch_size"])
+    cfg = {"grid_size": index_ops.grid_size_of(refcfg.CART_VOXEL, refcfg.CART_RANGE), "use_multi_sweeps": tag == "ms",
+           "use_image_feature": tag == "ms"}
+    with torch.no_grad():
+        res = model.spnet_forward(batch, p, cfg)
+    for k in ("point_out", "voxel_out", "aux_voxel_out"):
+        assert float((res[k] - torch.from_numpy(d[k])).abs().max()) <= 1e-4, k
+    assert np.array_equal(res["aux_voxel_coords"].numpy(), d["aux_voxel_coords"])
+
+
 def test_knn_oracle_semantics():
     from oracle.knn import knn_query
     xyz = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 2, 0], [5, 5, 5], [5, 5, 6], [1, 0, 0]])

@@ -8,6 +8,7 @@ from openseg3d_amd import batch as B, config, scene, segformer
 
 dev = torch.device("cuda:0")
 cfg = config.default_cfg()
+cfg.MODEL.SEGMENTOR = os.environ.get("SEGMENTOR", "segformer")
 ds = config.DatasetSpec(cfg)
 model = segformer.build_segmentor(cfg, ds).to(dev).train()
 opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
