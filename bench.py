@@ -45,6 +45,9 @@ def parse():
                          "(waymo_multi_sweeps.yaml + image features, 3 sweeps, use --batch 2)")
     ap.add_argument("--segmentor", choices=["segformer", "spnet"], default="segformer",
                     help="MODEL.SEGMENTOR (builder.py:8-23); segformer is the headline, spnet = SparseUnet + OCR")
+    ap.add_argument("--criterion", choices=["default", "ce"], default="default",
+                    help="default = MODEL.LOSSES of the reference config (ohem_ce + lovasz on the point, voxel and "
+                         "auxiliary heads, tools/train.py:71-110); ce = plain cross-entropy on the three heads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU-baseline sample (0 = whole scene)")
     return ap.parse_args()
@@ -224,8 +227,19 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True)
     labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
-    from openseg3d_amd import ops as _ops
-    ce = _ops.cross_entropy  # seg3d_cross_entropy_fwd/bwd (torch's nll_loss reduce kernels are single-block)
+    from openseg3d_amd import losses as _losses, ops as _ops
+    if args.criterion == "ce":
+        cfg.MODEL.LOSSES = {"ce": 1.0}
+    criterion = _losses.build_criterion(cfg, ds)  # builder.py:26-40
+    # voxel labels are part of the collated batch in the reference (WaymoDataset.prepare_voxel_labels in the loader
+    # workers): made once per resident scene group here, outside the timed region; the auxiliary-head labels are looked
+    # up inside the step, as tools/train.py:86-104 does
+    voxel_labels = []
+    for j in range(len(resident)):
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
+        cur = torch.nonzero(b["points"][:, 4] == 0).view(-1) if args.workload == "multi_sweeps" else None
+        voxel_labels.append(_ops.prepare_voxel_labels(b["point_voxel_ids"], labels[j], b["voxel_coords"].shape[0],
+                                                      ignore_index=ds.ignore_index, cur_point_indices=cur).long())
 
     def fwd_step(i):
         j = i % len(resident)
@@ -238,9 +252,8 @@ def main():
         b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
         opt.zero_grad(set_to_none=True)
         res = net(b)
-        vox_lab = labels[j][:1].expand(res["voxel_out"].shape[0])  # constant voxel labels: loss plumbing only
-        aux_lab = labels[j][:1].expand(res["aux_voxel_out"].shape[0])
-        loss = ce(res["point_out"], labels[j]) + ce(res["voxel_out"], vox_lab) + 0.4 * ce(res["aux_voxel_out"], aux_lab)
+        data = {"point_labels": labels[j], "voxel_labels": voxel_labels[j], "batch_size": b["batch_size"]}
+        loss = _losses.compute_loss(res, data, criterion, cfg)
         loss.backward()
         opt.step()
         return res
@@ -280,7 +293,7 @@ def main():
                                     "multi_sweeps": "waymo_multi_sweeps + image features (BASELINE configs[3], 3 sweeps)"
                                     }[args.workload] + ": synthetic 64-beam scene, "
                                    f"{pts_per_step[0]} pts/step/GPU, voxel {ds.voxel_size}, grid {ds.grid_size.tolist()}, "
-                                   f"{'forward-only eval' if not train else 'fwd+loss+bwd+SGD step'}",
+                                   f"{'forward-only eval' if not train else 'fwd + criterion (' + '+'.join(cfg.MODEL.LOSSES) + ' on 3 heads) + bwd + SGD step'}",
                        "mode": args.mode, "segmentor": args.segmentor, "scenes_per_step_per_gpu": args.batch,
                        "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}"},
             "fwd_only": {"value": round(n_pts_f / dt_f, 1), "unit": "points/s",

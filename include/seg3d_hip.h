@@ -370,17 +370,42 @@ int seg3d_voxel_majority_labels(const uint8_t* point_labels, const int32_t* orde
                                 int64_t n_voxels, int32_t ignore_index, uint8_t* voxel_labels, void* stream);
 
 /*
- * SURVEY 8(f)  cross-entropy term of the training loss (tools/train.py: nn.CrossEntropyLoss(ignore_index=...), mean
- * over the counted rows) on logits [n, c] with int64 labels; rows whose label is ignore_index (or outside [0, c))
- * contribute nothing.  forward: lse [n] kept for backward, stats = {mean loss, count}; backward: dlogits =
- * (softmax - onehot) * grad_out / count.  Deterministic (per-block partials, fixed-order finalize).
+ * SURVEY 8(f) rank 4  'ce' / 'ohem_ce' terms of build_criterion (seg3d/models/builder.py:26-40) on logits [n, c] with
+ * int64 labels; rows whose label is ignore_index (or outside [0, c)) contribute nothing.
+ *   keep_thresh <= 0 : nn.CrossEntropyLoss(ignore_index), mean over the counted rows
+ *   keep_thresh  > 0 : OHEMCrossEntropyLoss(keep_thresh) (seg3d/models/losses/ohem_cross_entropy_loss.py:23-38): only
+ *                      rows with softmax(logits)[label] < keep_thresh are counted
+ * forward: lse [n] kept for backward (log-sum-exp on counted rows, +inf on the others), stats = {mean loss, count}
+ * (mean = 0 when nothing is counted; torch returns NaN there); backward: dlogits = (softmax - onehot) * grad_out / count
+ * on counted rows, 0 elsewhere.  Deterministic (per-block partials, fixed-order finalize).
  */
 size_t seg3d_cross_entropy_workspace_bytes(int64_t n);
 int seg3d_cross_entropy_fwd(const float* logits, const int64_t* labels, int64_t n, int32_t c, int64_t ignore_index,
-                            float* lse, float* stats, void* workspace, size_t workspace_bytes, void* stream);
-int seg3d_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* lse, const float* stats,
-                            const float* grad_out, int64_t n, int32_t c, int64_t ignore_index, float* dlogits,
+                            float keep_thresh, float* lse, float* stats, void* workspace, size_t workspace_bytes,
                             void* stream);
+int seg3d_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* lse, const float* stats,
+                            const float* grad_out, int64_t n, int32_t c, float* dlogits, void* stream);
+
+/*
+ * SURVEY 8(f) rank 4  Lovasz-softmax term: LovaszLoss(ignore_index) as build_criterion makes it (multi_class, per_image
+ * False; seg3d/models/losses/lovasz_loss.py:13-26 lovasz_grad, :118-158 lovasz_softmax_flat, :268-290 forward) on logits
+ * [n, c <= 64] with int64 labels, n * c < 2^31.  All classes go through ONE device radix sort of (class, error) keys
+ * instead of c separate sorts; the jaccard differences use the reference's float32 arithmetic.
+ *   classes_mode 0 = 'present' (classes without a label in the batch are skipped), 1 = 'all'; include (nullable int32
+ *   [c], non-zero = averaged) is the explicit class list of the reference and overrides the presence test; class_weight
+ *   nullable float [c].  Rows with label == ignore_index take no part.
+ * forward : coef [n, c] (d loss_class / d prob, kept for backward), stats [2 + c] = {loss, classes averaged,
+ *           d loss / d loss_class per class}
+ * backward: dlogits [n, c] = softmax backward of coef * stats[2 + class] * grad_out[0]
+ * seg3d_lovasz_workspace_bytes asks rocPRIM for the sort's scratch size on the current device: 0 = invalid arguments or
+ * no device visible.
+ */
+size_t seg3d_lovasz_workspace_bytes(int64_t n, int32_t c);
+int seg3d_lovasz_softmax_fwd(const float* logits, const int64_t* labels, int64_t n, int32_t c, int64_t ignore_index,
+                             int32_t classes_mode, const int32_t* include, const float* class_weight, float* coef,
+                             float* stats, void* workspace, size_t workspace_bytes, void* stream);
+int seg3d_lovasz_softmax_bwd(const float* logits, const float* coef, const float* stats, const float* grad_out,
+                             int64_t n, int32_t c, float* dlogits, void* stream);
 
 #ifdef __cplusplus
 }

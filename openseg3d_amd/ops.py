@@ -987,18 +987,17 @@ def aux_voxel_labels(voxel_coords, aux_voxel_coords, voxel_labels, batch_size, v
 # ------------------------------------------------------------------------------------------ loss
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index):
+    def forward(ctx, logits, labels, ignore_index, keep_thresh):
         x = _f32c(logits)
         n, c = x.shape
         lab = labels.contiguous()
         lse = torch.empty((n,), dtype=torch.float32, device=x.device)
         stats = torch.empty((2,), dtype=torch.float32, device=x.device)
         ws_bytes = _lib.query("seg3d_cross_entropy_workspace_bytes", n)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-        _lib.call("seg3d_cross_entropy_fwd", _ptr(x), _ptr(lab), n, c, int(ignore_index), _ptr(lse), _ptr(stats), _ptr(ws),
-                  ws_bytes, _stream())
+        ws = _workspace(ws_bytes, x.device)
+        _lib.call("seg3d_cross_entropy_fwd", _ptr(x), _ptr(lab), n, c, int(ignore_index), float(keep_thresh), _ptr(lse),
+                  _ptr(stats), _ptr(ws), ws_bytes, _stream())
         ctx.save_for_backward(x, lab, lse, stats)
-        ctx.ignore_index = int(ignore_index)
         return stats[0]
 
     @staticmethod
@@ -1007,15 +1006,71 @@ class _CrossEntropyFn(torch.autograd.Function):
         n, c = x.shape
         dx = torch.empty_like(x)
         gg = _f32c(g.reshape(1))
-        _lib.call("seg3d_cross_entropy_bwd", _ptr(x), _ptr(lab), _ptr(lse), _ptr(stats), _ptr(gg), n, c, ctx.ignore_index,
-                  _ptr(dx), _stream())
-        return dx, None, None
+        _lib.call("seg3d_cross_entropy_bwd", _ptr(x), _ptr(lab), _ptr(lse), _ptr(stats), _ptr(gg), n, c, _ptr(dx), _stream())
+        return dx, None, None, None
 
 
-def cross_entropy(logits, labels, ignore_index=-100):
+def _loss_args_ok(logits, labels, max_classes):
+    return (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64
+            and labels.dim() == 1 and labels.shape[0] == logits.shape[0] and logits.shape[1] <= max_classes)
+
+
+def cross_entropy(logits, labels, ignore_index=-100, keep_thresh=None):
     """``F.cross_entropy(logits, labels, ignore_index=...)`` (mean reduction) for float32 [n, C] logits and int64 labels
-    on the GPU, in one pass each way; anything else goes to torch."""
-    if not (logits.is_cuda and logits.dim() == 2 and logits.dtype == torch.float32 and labels.dtype == torch.int64
-            and labels.dim() == 1 and labels.shape[0] == logits.shape[0] and logits.shape[1] <= 4096):
-        return torch.nn.functional.cross_entropy(logits, labels, ignore_index=ignore_index)
-    return _CrossEntropyFn.apply(logits, labels, ignore_index)
+    on the GPU, in one pass each way.  ``keep_thresh``: OHEMCrossEntropyLoss(keep_thresh) of the reference
+    (ohem_cross_entropy_loss.py:23-38) -- only rows whose softmax probability of the target is below it are averaged.
+    Returns 0 (not NaN) when no row is counted."""
+    if not _loss_args_ok(logits, labels, 4096):
+        raise ValueError("cross_entropy: float32 [n, C <= 4096] logits and int64 [n] labels on the GPU")
+    return _CrossEntropyFn.apply(logits, labels, ignore_index, keep_thresh if keep_thresh else 0.0)
+
+
+class _LovaszSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, classes_mode, include, class_weight):
+        x = _f32c(logits)
+        n, c = x.shape
+        lab = labels.contiguous()
+        coef = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        stats = torch.empty((2 + c,), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_lovasz_workspace_bytes", n, c)
+        if ws_bytes == 0:
+            raise _lib.Seg3dError(f"seg3d_lovasz_workspace_bytes({n}, {c}) = 0: n * c must stay below 2^31, c <= 64")
+        ws = _workspace(ws_bytes, x.device)
+        _lib.call("seg3d_lovasz_softmax_fwd", _ptr(x), _ptr(lab), n, c, int(ignore_index), int(classes_mode),
+                  _ptr(include) if include is not None else None, _ptr(class_weight) if class_weight is not None else None,
+                  _ptr(coef), _ptr(stats), _ptr(ws), ws_bytes, _stream())
+        ctx.save_for_backward(x, coef, stats)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, coef, stats = ctx.saved_tensors
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        gg = _f32c(g.reshape(1))
+        _lib.call("seg3d_lovasz_softmax_bwd", _ptr(x), _ptr(coef), _ptr(stats), _ptr(gg), n, c, _ptr(dx), _stream())
+        return dx, None, None, None, None, None
+
+
+def lovasz_softmax(logits, labels, ignore_index=255, classes="present", class_weight=None):
+    """Lovasz-softmax of the reference's ``LovaszLoss`` defaults (multi_class, per_image=False;
+    seg3d/models/losses/lovasz_loss.py:118-158, 268-290) on float32 [n, C <= 64] logits and int64 labels: softmax, then
+    for every class the Lovasz extension of the Jaccard loss over the descending errors, mean over the chosen classes
+    ('present' | 'all' | list of class ids).  One device sort for all classes (seg3d_lovasz_softmax_fwd)."""
+    if not _loss_args_ok(logits, labels, 64):
+        raise ValueError("lovasz_softmax: float32 [n, C <= 64] logits and int64 [n] labels on the GPU")
+    c = logits.shape[1]
+    include = None
+    if classes == "present":
+        mode = 0
+    elif classes == "all":
+        mode = 1
+    else:
+        mode = 1
+        include = torch.zeros((c,), dtype=torch.int32)
+        include[torch.as_tensor(list(classes), dtype=torch.long)] = 1
+        include = include.to(logits.device)
+    if class_weight is not None:
+        class_weight = _f32c(torch.as_tensor(class_weight, dtype=torch.float32, device=logits.device))
+    return _LovaszSoftmaxFn.apply(logits, labels, ignore_index, mode, include, class_weight)

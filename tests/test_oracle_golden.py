@@ -143,6 +143,24 @@ def test_spnet_matches_reference_model_code(golden_dir, tag):
     assert np.array_equal(res["aux_voxel_coords"].numpy(), d["aux_voxel_coords"])
 
 
+def test_losses_match_reference_loss_modules(golden_dir):
+    """Oracle OHEM-CE / Lovasz-softmax (value and gradient) vs the reference's own loss classes (make_golden.gen_losses)."""
+    from oracle import losses as L
+    d = np.load(os.path.join(golden_dir, "losses.npz"))
+    labels = torch.from_numpy(d["labels"])
+    cases = {"ohem": lambda x: L.ohem_cross_entropy(x, labels, 0.7),
+             "lovasz": lambda x: L.lovasz_softmax(x, labels),
+             "lovasz_all": lambda x: L.lovasz_softmax(x, labels, classes="all"),
+             "lovasz_list": lambda x: L.lovasz_softmax(x, labels, classes=[0, 3, 7, 21]),
+             "lovasz_weighted": lambda x: L.lovasz_softmax(x, labels, class_weight=d["class_weight"].tolist())}
+    for name, fn in cases.items():
+        x = torch.from_numpy(d["logits"]).clone().requires_grad_(True)
+        loss = fn(x)
+        loss.backward()
+        assert abs(float(loss) - float(d[name])) <= 1e-6, name
+        assert float((x.grad - torch.from_numpy(d[name + "_grad"])).abs().max()) <= 1e-8, name
+
+
 def test_knn_oracle_semantics():
     from oracle.knn import knn_query
     xyz = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 2, 0], [5, 5, 5], [5, 5, 6], [1, 0, 0]])
