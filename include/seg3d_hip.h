@@ -328,29 +328,35 @@ int seg3d_knn_query(const float* xyz, int64_t n, const float* new_xyz, int64_t m
                     const int32_t* new_offset, int32_t batch_size, int32_t k, int32_t* idx, float* dist2,
                     void* stream);
 
-/* Grid-accelerated exact kNN (same results and tie rule as seg3d_knn_query) for large clouds, in three steps around
- * a caller-side sort:
- *   seg3d_knn_cell_keys   keys[i] = (batch << 48 | cx << 32 | cy << 16 | cz), c* = floor(p / cell) + 32768 (clamped);
- *   [caller: sort keys, gather points into that order (sorted_xyz [n,3], src_index = original row), unique keys ->
- *    unique_keys [n_cells], cell_start [n_cells + 1]]
- *   seg3d_knn_grid_build  open-addressing table unique key -> cell ordinal; capacity = power of two >= 2 n_cells
- *                         (table_keys: capacity x 8 B, table_vals: capacity x 4 B)
- *   seg3d_knn_grid_query  per query: cube shells around its cell until the k-th distance is below the shell bound; up to
- *                         four grids, fine to coarse (lidar density falls as 1/r^2): a query still open after a level's
- *                         max_ring shells restarts on the next level, and scans its whole segment after the last one.
- *                         When every level's cell is exactly 8x the previous one, a coarse cell holding > 128 points is
- *                         searched through its sub-cells, pruned by box distance against the current k-th distance.
- *                         batch_size <= 255.  `levels` is a HOST array. */
-int seg3d_knn_cell_keys(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell,
-                        int64_t* keys, void* stream);
-int seg3d_knn_grid_build(const int64_t* unique_keys, int64_t n_cells, void* table_keys, int32_t* table_vals,
-                         int64_t capacity, void* stream);
+/* Grid-accelerated exact kNN (same results and tie rule as seg3d_knn_query) for large clouds.  Nothing here reads a
+ * device value on the host: a whole query is a fixed sequence of launches.
+ *   seg3d_knn_level_build  one grid level over xyz [n,3]: key = (batch << 48 | cx << 32 | cy << 16 | cz), c* =
+ *                          floor(p / cell) + 32768 (clamped); device radix sort of (key, row); sorted_xyz [n,3] = points
+ *                          in cell order, src_index [n] = their original rows; for the first point of every cell
+ *                          (sorted position s): cell_end[s] = end of the cell's run, and key -> s goes into the
+ *                          open-addressing table (capacity: power of two >= 2 n; table_keys capacity x 8 B,
+ *                          table_vals capacity x 4 B).  Workspace: seg3d_knn_level_workspace_bytes(n) (0 = invalid n or
+ *                          no device visible -- the sort's scratch size comes from rocPRIM).
+ *   seg3d_knn_query_order  order [m] = query rows sorted by their cell key on a grid of the given cell size (neighbouring
+ *                          lanes then walk the same cells); same workspace query with n = m.
+ *   seg3d_knn_grid_query   per query: cube shells around its cell until the k-th distance is below the shell bound; up to
+ *                          four grids, fine to coarse (lidar density falls as 1/r^2): a query still open after a level's
+ *                          max_ring shells restarts on the next level, and scans its whole segment after the last one.
+ *                          When every level's cell is exactly 8x the previous one, a coarse cell holding > 128 points is
+ *                          searched through its sub-cells, pruned by box distance against the current k-th distance.
+ *                          batch_size <= 255.  `levels` is a HOST array. */
+size_t seg3d_knn_level_workspace_bytes(int64_t n);
+int seg3d_knn_level_build(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell,
+                          float* sorted_xyz, int32_t* src_index, int32_t* cell_end, void* table_keys, int32_t* table_vals,
+                          int64_t capacity, void* workspace, size_t workspace_bytes, void* stream);
+int seg3d_knn_query_order(const float* new_xyz, int64_t m, const int32_t* new_offset, int32_t batch_size, float cell,
+                          int32_t* order, void* workspace, size_t workspace_bytes, void* stream);
 typedef struct {
   const float* sorted_xyz;     /* [n,3] points in this level's cell order */
   const int32_t* src_index;    /* [n] original row of each sorted point */
-  const int32_t* cell_start;   /* [n_cells + 1] */
+  const int32_t* cell_end;     /* [n] valid at the first sorted position of every cell */
   const void* table_keys;      /* capacity x 8 B */
-  const int32_t* table_vals;   /* capacity x 4 B */
+  const int32_t* table_vals;   /* capacity x 4 B: first sorted position of the cell */
   int64_t capacity;
   float cell;                  /* metres */
   int32_t max_ring;            /* shells walked on this level (<= 16) */

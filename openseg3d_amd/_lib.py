@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -67,13 +67,14 @@ SIGNATURES = {
     "seg3d_segment_reduce_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _p]),
     "seg3d_voxel_majority_labels": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "seg3d_cross_entropy_workspace_bytes": (ctypes.c_size_t, [_i64]),
-    "seg3d_cross_entropy_fwd": (ctypes.c_int, [_p, _p, _i64, _i32, _i64, ctypes.c_float, _p, _p, _p, ctypes.c_size_t, _p]),
+    "seg3d_cross_entropy_fwd": (ctypes.c_int, [_p, _p, _i64, _i32, _i64, _f, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_cross_entropy_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "seg3d_lovasz_workspace_bytes": (ctypes.c_size_t, [_i64, _i32]),
     "seg3d_lovasz_softmax_fwd": (ctypes.c_int, [_p, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_lovasz_softmax_bwd": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
-    "seg3d_knn_cell_keys": (ctypes.c_int, [_p, _i64, _p, _i32, _f, _p, _p]),
-    "seg3d_knn_grid_build": (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p]),
+    "seg3d_knn_level_workspace_bytes": (ctypes.c_size_t, [_i64]),
+    "seg3d_knn_level_build": (ctypes.c_int, [_p, _i64, _p, _i32, _f, _p, _p, _p, _p, _p, _i64, _p, ctypes.c_size_t, _p]),
+    "seg3d_knn_query_order": (ctypes.c_int, [_p, _i64, _p, _i32, _f, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_knn_grid_query": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_knn_query": (ctypes.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_gather_rows": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),

@@ -13,6 +13,10 @@
 // 1024-point tiles staged through LDS (12 KiB, coalesced loads, broadcast reads), each lane keeps its K best
 // in a sorted register list (insertion only when a candidate beats the current worst).  O(m*n_b) like the
 // reference; a grid-hash variant is the follow-up for the 180k x 180k fusion query.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.hpp"
 
 namespace {
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void knn_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // Grid-accelerated exact variant (same results, same tie rule) for large clouds: the 180k x 180k fusion query costs
 // 46 ms by brute force.  Points are binned into cubic cells (key = batch | cx | cy | cz, 16 bits each), sorted by key
-// (caller: torch.sort), the non-empty cells go into an open-addressing table, and every query walks the cube shells
+// (rocPRIM device radix sort), the non-empty cells go into an open-addressing table, and every query walks the cube shells
 // r = 0, 1, 2, .. around its own cell until its K-th distance is strictly below (r * cell)^2 -- every point not yet
 // visited is at least that far.  Queries that have not converged after kMaxRing shells (isolated points) scan their
 // whole batch segment.  Entries are ordered by (d2, original index), i.e. exactly the brute-force order.
@@ -114,20 +118,40 @@ __device__ __forceinline__ unsigned long long cell_key(int b, int cx, int cy, in
 }
 
 __global__ __launch_bounds__(kThreads) void knn_cell_keys(const float* __restrict__ xyz, int n, const int32_t* __restrict__ offset,
-                                                          int b, float inv_cell, int64_t* __restrict__ keys) {
+                                                          int b, float inv_cell, unsigned long long* __restrict__ keys,
+                                                          uint32_t* __restrict__ rows) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const int seg = segment_of(i, offset, b);
-    keys[i] = (int64_t)cell_key(seg, cell_of(xyz[3 * (int64_t)i], inv_cell), cell_of(xyz[3 * (int64_t)i + 1], inv_cell),
-                                cell_of(xyz[3 * (int64_t)i + 2], inv_cell));
+    keys[i] = cell_key(seg, cell_of(xyz[3 * (int64_t)i], inv_cell), cell_of(xyz[3 * (int64_t)i + 1], inv_cell),
+                       cell_of(xyz[3 * (int64_t)i + 2], inv_cell));
+    rows[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(kThreads) void knn_table_insert(const int64_t* __restrict__ ukeys, int n_cells,
+// after the (key, row) sort: gather the points into cell order; the first point of every cell finds the end of its
+// run by bisection and publishes key -> first position
+__global__ __launch_bounds__(kThreads) void knn_level_finish(const unsigned long long* __restrict__ skeys,
+                                                             const uint32_t* __restrict__ srows, const float* __restrict__ xyz,
+                                                             int n, float* __restrict__ sxyz, int32_t* __restrict__ src,
+                                                             int32_t* __restrict__ cell_end,
                                                              unsigned long long* __restrict__ tkeys,
                                                              int32_t* __restrict__ tvals, unsigned cap_mask) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n_cells) return;
-    const unsigned long long key = (unsigned long long)ukeys[i];
+    if (i >= n) return;
+    const unsigned long long key = skeys[i];
+    const uint32_t r = srows[i];
+    src[i] = (int32_t)r;
+    sxyz[3 * (int64_t)i] = xyz[3 * (int64_t)r];
+    sxyz[3 * (int64_t)i + 1] = xyz[3 * (int64_t)r + 1];
+    sxyz[3 * (int64_t)i + 2] = xyz[3 * (int64_t)r + 2];
+    if (i > 0 && skeys[i - 1] == key) return;
+    int lo = i + 1, hi = n;  // first position in (i, n] whose key differs
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (skeys[mid] == key) lo = mid + 1;
+        else hi = mid;
+    }
+    cell_end[i] = lo;
     unsigned slot = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & cap_mask;
     for (;;) {  // unique keys, table at most half full: terminates
         const unsigned long long prev = atomicCAS(&tkeys[slot], ~0ull, key);
@@ -139,10 +163,15 @@ __global__ __launch_bounds__(kThreads) void knn_table_insert(const int64_t* __re
     }
 }
 
+__global__ __launch_bounds__(kThreads) void knn_copy_order(const uint32_t* __restrict__ srows, int m, int32_t* __restrict__ order) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < m) order[i] = (int32_t)srows[i];
+}
+
 struct GridLevel {
     const float* sxyz;        // points in this level's cell order
     const int32_t* src;       // original row of each sorted point
-    const int32_t* cell_start;
+    const int32_t* cell_end;  // [n], valid at the first sorted position of a cell
     const unsigned long long* tkeys;
     const int32_t* tvals;
     unsigned cap_mask;
@@ -219,8 +248,7 @@ struct KnnState {
             if (tk == ~0ull) return;  // empty cell
             slot = (slot + 1) & lv.cap_mask;
         }
-        const int ci = lv.tvals[slot];
-        const int c0 = lv.cell_start[ci], c1 = lv.cell_start[ci + 1];
+        const int c0 = lv.tvals[slot], c1 = lv.cell_end[c0];
         if constexpr (L > 0) {
             if (g.nested && c1 - c0 > kDenseCell) {
                 const float s = g.lv[L - 1].cell;
@@ -317,30 +345,101 @@ extern "C" int seg3d_knn_query(const float* xyz, int64_t n, const float* new_xyz
     return SEG3D_OK;
 }
 
-/* Grid-accelerated exact kNN, three steps around a caller-side sort (see knn.hip):
- *   keys[i] = cell key of xyz row i (batch | cx | cy | cz);  table = open-addressing map of the unique keys;
- *   query over the points gathered into cell order. */
-extern "C" int seg3d_knn_cell_keys(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell,
-                                   int64_t* keys, void* stream) {
+namespace {
+
+using SortKey = unsigned long long;
+constexpr unsigned kKeyBits = 56;  // batch (8) | cx (16) | cy (16) | cz (16)
+
+bool sort_scratch_bytes(int64_t n, size_t* bytes) {
+    *bytes = 0;
+    if (n == 0) return true;
+    rocprim::double_buffer<SortKey> k(nullptr, nullptr);
+    rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
+    return rocprim::radix_sort_pairs(nullptr, *bytes, k, v, (size_t)n, 0u, kKeyBits) == hipSuccess;
+}
+
+struct SortBuffers {
+    SortKey *k0, *k1;
+    uint32_t *v0, *v1;
+    void* tmp;
+    size_t tmp_bytes;
+};
+
+bool carve_sort(void* workspace, size_t workspace_bytes, int64_t n, SortBuffers* sb) {
+    if (!sort_scratch_bytes(n, &sb->tmp_bytes)) return false;
+    if (!workspace || workspace_bytes < seg3d_knn_level_workspace_bytes(n)) return false;
+    WsCarver ws(workspace);
+    sb->k0 = ws.take<SortKey>((size_t)n);
+    sb->k1 = ws.take<SortKey>((size_t)n);
+    sb->v0 = ws.take<uint32_t>((size_t)n);
+    sb->v1 = ws.take<uint32_t>((size_t)n);
+    sb->tmp = ws.take<char>(sb->tmp_bytes);
+    return true;
+}
+
+// keys + rows of xyz on a grid of `cell`, sorted by key; *skeys / *srows point at the sorted halves
+int sorted_cells(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell, SortBuffers& sb,
+                 hipStream_t st, const SortKey** skeys, const uint32_t** srows) {
+    hipLaunchKernelGGL(knn_cell_keys, dim3((unsigned)ceil_div64(n, kThreads)), dim3(kThreads), 0, st, xyz, (int)n, offset,
+                       batch_size, 1.0f / cell, sb.k0, sb.v0);
+    SEG3D_CHECK_LAUNCH();
+    rocprim::double_buffer<SortKey> kb(sb.k0, sb.k1);
+    rocprim::double_buffer<uint32_t> vb(sb.v0, sb.v1);
+    size_t bytes = sb.tmp_bytes;
+    if (rocprim::radix_sort_pairs(sb.tmp, bytes, kb, vb, (size_t)n, 0u, kKeyBits, st) != hipSuccess) return SEG3D_ELAUNCH;
+    *skeys = kb.current();
+    *srows = vb.current();
+    return SEG3D_OK;
+}
+
+}  // namespace
+
+/* Grid-accelerated exact kNN (see the kernels above): level build and query order are launch sequences without any
+ * host read-back; the sort is rocPRIM's device radix sort of (cell key, row). */
+extern "C" size_t seg3d_knn_level_workspace_bytes(int64_t n) {
+    if (n < 0 || n >= (int64_t)0x7FFFFFF0) return 0;
+    size_t tmp = 0;
+    if (!sort_scratch_bytes(n, &tmp)) return 0;
+    return 2 * align_up((size_t)n * sizeof(SortKey), 256) + 2 * align_up((size_t)n * sizeof(uint32_t), 256) + align_up(tmp, 256) + 256;
+}
+
+extern "C" int seg3d_knn_level_build(const float* xyz, int64_t n, const int32_t* offset, int32_t batch_size, float cell,
+                                     float* sorted_xyz, int32_t* src_index, int32_t* cell_end, void* table_keys,
+                                     int32_t* table_vals, int64_t capacity, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     if (n < 0 || batch_size <= 0 || batch_size > 255 || !(cell > 0.f) || n >= (int64_t)0x7FFFFFF0) return SEG3D_EINVAL;
+    if (capacity < 2 * n || capacity <= 0 || (capacity & (capacity - 1)) || capacity > (1ll << 31)) return SEG3D_EINVAL;
+    if (!table_keys || !table_vals) return SEG3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(table_keys, 0xFF, (size_t)capacity * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
     if (n == 0) return SEG3D_OK;
-    if (!xyz || !offset || !keys) return SEG3D_EINVAL;
-    hipLaunchKernelGGL(knn_cell_keys, dim3((unsigned)ceil_div64(n, kThreads)), dim3(kThreads), 0, as_stream(stream), xyz, (int)n,
-                       offset, batch_size, 1.0f / cell, keys);
+    if (!xyz || !offset || !sorted_xyz || !src_index || !cell_end) return SEG3D_EINVAL;
+    SortBuffers sb;
+    if (!carve_sort(workspace, workspace_bytes, n, &sb)) return SEG3D_EWORKSPACE;
+    const SortKey* skeys;
+    const uint32_t* srows;
+    const int rc = sorted_cells(xyz, n, offset, batch_size, cell, sb, st, &skeys, &srows);
+    if (rc != SEG3D_OK) return rc;
+    hipLaunchKernelGGL(knn_level_finish, dim3((unsigned)ceil_div64(n, kThreads)), dim3(kThreads), 0, st, skeys, srows, xyz, (int)n,
+                       sorted_xyz, src_index, cell_end, static_cast<unsigned long long*>(table_keys), table_vals,
+                       (unsigned)(capacity - 1));
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
 
-extern "C" int seg3d_knn_grid_build(const int64_t* unique_keys, int64_t n_cells, void* table_keys, int32_t* table_vals,
-                                    int64_t capacity, void* stream) {
-    if (n_cells < 0 || capacity < 2 * n_cells || capacity <= 0 || (capacity & (capacity - 1)) || capacity > (1ll << 30))
-        return SEG3D_EINVAL;
-    if (!table_keys || !table_vals || (n_cells > 0 && !unique_keys)) return SEG3D_EINVAL;
+extern "C" int seg3d_knn_query_order(const float* new_xyz, int64_t m, const int32_t* new_offset, int32_t batch_size, float cell,
+                                     int32_t* order, void* workspace, size_t workspace_bytes, void* stream) {
+    if (m < 0 || batch_size <= 0 || batch_size > 255 || !(cell > 0.f) || m >= (int64_t)0x7FFFFFF0) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!new_xyz || !new_offset || !order) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(table_keys, 0xFF, (size_t)capacity * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (n_cells == 0) return SEG3D_OK;
-    hipLaunchKernelGGL(knn_table_insert, dim3((unsigned)ceil_div64(n_cells, kThreads)), dim3(kThreads), 0, st, unique_keys,
-                       (int)n_cells, static_cast<unsigned long long*>(table_keys), table_vals, (unsigned)(capacity - 1));
+    SortBuffers sb;
+    if (!carve_sort(workspace, workspace_bytes, m, &sb)) return SEG3D_EWORKSPACE;
+    const SortKey* skeys;
+    const uint32_t* srows;
+    const int rc = sorted_cells(new_xyz, m, new_offset, batch_size, cell, sb, st, &skeys, &srows);
+    if (rc != SEG3D_OK) return rc;
+    hipLaunchKernelGGL(knn_copy_order, dim3((unsigned)ceil_div64(m, kThreads)), dim3(kThreads), 0, st, srows, (int)m, order);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -361,10 +460,10 @@ extern "C" int seg3d_knn_grid_query(const seg3d_knn_level* levels, int32_t n_lev
         if (fabsf(levels[l].cell - 8.0f * levels[l - 1].cell) > 1e-6f * levels[l].cell) g.nested = 0;
     for (int l = 0; l < n_levels; ++l) {
         const seg3d_knn_level& a = levels[l];
-        if (!a.sorted_xyz || !a.src_index || !a.cell_start || !a.table_keys || !a.table_vals || a.capacity <= 0 ||
+        if (!a.sorted_xyz || !a.src_index || !a.cell_end || !a.table_keys || !a.table_vals || a.capacity <= 0 ||
             (a.capacity & (a.capacity - 1)) || !(a.cell > 0.f) || a.max_ring < 0 || a.max_ring > 16)
             return SEG3D_EINVAL;
-        g.lv[l] = GridLevel{a.sorted_xyz, a.src_index, a.cell_start, static_cast<const unsigned long long*>(a.table_keys),
+        g.lv[l] = GridLevel{a.sorted_xyz, a.src_index, a.cell_end, static_cast<const unsigned long long*>(a.table_keys),
                             a.table_vals, (unsigned)(a.capacity - 1), a.cell, a.max_ring};
     }
     hipStream_t st = as_stream(stream);

@@ -883,15 +883,16 @@ if os.environ.get("SEG3D_KNN_LEVELS"):  # e.g. "0.1:2,0.5:3,3.0:4"
 
 
 class _KnnLevel(ctypes.Structure):  # seg3d_knn_level
-    _fields_ = [("sorted_xyz", ctypes.c_void_p), ("src_index", ctypes.c_void_p), ("cell_start", ctypes.c_void_p),
+    _fields_ = [("sorted_xyz", ctypes.c_void_p), ("src_index", ctypes.c_void_p), ("cell_end", ctypes.c_void_p),
                 ("table_keys", ctypes.c_void_p), ("table_vals", ctypes.c_void_p), ("capacity", ctypes.c_int64),
                 ("cell", ctypes.c_float), ("max_ring", ctypes.c_int32)]
 
 
-def knn_query(nsample, xyz, new_xyz, offset, new_offset):
+def knn_query(nsample, xyz, new_xyz, offset, new_offset, levels=None):
     """``seg3d.ops.knn_query`` (knn_query.py:7-24): (idx int32 [m, nsample], dist float32 [m, nsample] = sqrt(d2)).
     xyz / new_xyz: contiguous float32 [*, 3]; offset / new_offset: cumulative int32 counts per sample.
-    Non-differentiable, like the reference Function (it defines no backward)."""
+    Non-differentiable, like the reference Function (it defines no backward).  ``levels``: ((cell, shells), ...) of the
+    grid search, fine to coarse (default KNN_GRID_LEVELS); the result does not depend on it."""
     if new_xyz is None:
         new_xyz = xyz
     _need_gpu(xyz, new_xyz, offset, new_offset)
@@ -908,36 +909,34 @@ def knn_query(nsample, xyz, new_xyz, offset, new_offset):
     idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
     d2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
     if n >= KNN_GRID_MIN_POINTS and nsample <= 64 and off.shape[0] <= 255:
-        # exact grid search (same results): per level bin, sort by cell, table of non-empty cells; shell walk per query
+        # exact grid search (same results): per level one launch sequence (keys, device sort, gather + cell table),
+        # then one query kernel; no device value is read on the host anywhere
         dev = xyz.device
-        xyz3 = xyz.reshape(-1)[: 3 * n].view(n, 3)
-        keep, levels = [], (_KnnLevel * len(KNN_GRID_LEVELS))()
-        for li, (cell, max_ring) in enumerate(KNN_GRID_LEVELS):
-            keys = torch.empty((n,), dtype=torch.int64, device=dev)
-            _lib.call("seg3d_knn_cell_keys", _ptr(xyz3), n, _ptr(off), off.shape[0], float(cell), _ptr(keys), _stream())
-            skeys, order = torch.sort(keys)
-            sorted_xyz = xyz3.index_select(0, order).contiguous()
-            src_index = order.to(torch.int32)
-            ukeys, counts = torch.unique_consecutive(skeys, return_counts=True)
-            n_cells = int(ukeys.shape[0])
-            cell_start = torch.zeros((n_cells + 1,), dtype=torch.int32, device=dev)
-            cell_start[1:] = torch.cumsum(counts, 0)
-            cap = 1 << max(4, (2 * n_cells - 1).bit_length())
+        grid = tuple(levels) if levels is not None else KNN_GRID_LEVELS
+        ws_bytes = _lib.query("seg3d_knn_level_workspace_bytes", max(n, m))
+        if ws_bytes == 0:
+            raise _lib.Seg3dError("seg3d_knn_level_workspace_bytes = 0: no device visible or too many points")
+        ws = _workspace(ws_bytes, dev)
+        cap = 1 << max(4, (2 * n - 1).bit_length())
+        keep, lv = [], (_KnnLevel * len(grid))()
+        for li, (cell, max_ring) in enumerate(grid):
+            sorted_xyz = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            src_index = torch.empty((n,), dtype=torch.int32, device=dev)
+            cell_end = torch.empty((n,), dtype=torch.int32, device=dev)
             tkeys = torch.empty((cap,), dtype=torch.int64, device=dev)
             tvals = torch.empty((cap,), dtype=torch.int32, device=dev)
-            _lib.call("seg3d_knn_grid_build", _ptr(ukeys), n_cells, _ptr(tkeys), _ptr(tvals), cap, _stream())
-            keep.append((sorted_xyz, src_index, cell_start, tkeys, tvals))
-            levels[li] = _KnnLevel(sorted_xyz.data_ptr(), src_index.data_ptr(), cell_start.data_ptr(), tkeys.data_ptr(),
-                                   tvals.data_ptr(), cap, float(cell), int(max_ring))
+            _lib.call("seg3d_knn_level_build", _ptr(xyz), n, _ptr(off), off.shape[0], float(cell), _ptr(sorted_xyz),
+                      _ptr(src_index), _ptr(cell_end), _ptr(tkeys), _ptr(tvals), cap, _ptr(ws), ws_bytes, _stream())
+            keep.append((sorted_xyz, src_index, cell_end, tkeys, tvals))
+            lv[li] = _KnnLevel(sorted_xyz.data_ptr(), src_index.data_ptr(), cell_end.data_ptr(), tkeys.data_ptr(),
+                               tvals.data_ptr(), cap, float(cell), int(max_ring))
         if new_xyz.data_ptr() == xyz.data_ptr() and m == n:
             qorder = keep[0][1]  # self-query: the points' own finest-level cell order
         else:
-            q3 = new_xyz.reshape(-1)[: 3 * m].view(m, 3)
-            qkeys = torch.empty((m,), dtype=torch.int64, device=dev)
-            _lib.call("seg3d_knn_cell_keys", _ptr(q3), m, _ptr(noff), noff.shape[0], float(KNN_GRID_LEVELS[0][0]), _ptr(qkeys),
-                      _stream())
-            qorder = torch.sort(qkeys)[1].to(torch.int32)
-        _lib.call("seg3d_knn_grid_query", ctypes.cast(levels, ctypes.c_void_p), len(KNN_GRID_LEVELS), _ptr(new_xyz),
+            qorder = torch.empty((m,), dtype=torch.int32, device=dev)
+            _lib.call("seg3d_knn_query_order", _ptr(new_xyz), m, _ptr(noff), noff.shape[0], float(grid[0][0]), _ptr(qorder),
+                      _ptr(ws), ws_bytes, _stream())
+        _lib.call("seg3d_knn_grid_query", ctypes.cast(lv, ctypes.c_void_p), len(grid), _ptr(new_xyz),
                   _ptr(qorder), m, _ptr(off), _ptr(noff), off.shape[0], int(nsample), _ptr(idx), _ptr(d2), _stream())
         return idx, torch.sqrt(d2)
     _lib.call("seg3d_knn_query", _ptr(xyz), n, _ptr(new_xyz), m, _ptr(off), _ptr(noff), off.shape[0], int(nsample),
@@ -980,7 +979,11 @@ def aux_voxel_labels(voxel_coords, aux_voxel_coords, voxel_labels, batch_size, v
     aux_centers = get_voxel_centers(aux_voxel_coords[:, 1:], aux_scale, voxel_size, point_cloud_range).contiguous()
     off = torch.cumsum(torch.bincount(voxel_coords[:, 0].long(), minlength=batch_size), 0).int()
     aux_off = torch.cumsum(torch.bincount(aux_voxel_coords[:, 0].long(), minlength=batch_size), 0).int()
-    idx, _ = knn_query(1, centers, aux_centers, off, aux_off)
+    # grid for this lookup: one fine voxel per finest cell, one coarse voxel per middle cell (every coarse site has a
+    # fine voxel within ~2 coarse pitches: measured 0.96 ms vs 2.45 ms with the point-cloud default on the headline
+    # scene); the third level only guards against a whole-segment scan on unusual inputs
+    pitch = float(max(voxel_size))
+    idx, _ = knn_query(1, centers, aux_centers, off, aux_off, levels=((pitch, 0), (8 * pitch, 3), (64 * pitch, 2)))
     return voxel_labels[idx.reshape(-1).long()]
 
 
