@@ -239,7 +239,8 @@ int seg3d_pos_embed(const int32_t* in_win, int64_t m, const int32_t* win_xyz /*h
  * (tile_item) and one wave per (16-query group, head) (qg_item); n_tiles / n_qgroups are counts[2..3] of
  * seg3d_window_partition.
  * Backward takes the forward's out and lse, returns gradients w.r.t. the raw q, k, v (through the
- * normalisation) and adds the tau gradient into dtau[0] (caller zeroes it).
+ * normalisation) and stores the tau gradient in dtau[0] (per-wave partials in the workspace, summed in a
+ * fixed order: the whole backward is free of atomics and identical from run to run).
  */
 size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t n_tiles, int32_t heads, int32_t dh);
 int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
@@ -270,6 +271,8 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
  * BatchNorm1d (+ residual) (+ ReLU) of the conv blocks / point MLPs (spconv_utils.py:13-32,
  * pointtransformer.py:47-66, segformer.py:21-76):
  *     seg3d_colstats   sums[0..c) = sum_r (x - x[0]), sums[c..2c) = sum_r (x - x[0])^2   (shifted, cancellation-free)
+ *                      per-block partial sums in the workspace (seg3d_batchnorm_workspace_bytes), summed in a fixed
+ *                      order: no atomics, results are identical from run to run
  *     seg3d_batchnorm_stats  colstats + one finalize pass: stats [6][c] = {scratch, scratch, mean, rstd (biased
  *                      variance), scale = gamma*rstd, shift = beta - mean*scale}; running_mean / running_var (may be
  *                      NULL) updated in place with `momentum` (unbiased variance), as torch.nn.BatchNorm1d does
@@ -285,14 +288,17 @@ size_t seg3d_layernorm_bwd_workspace_bytes(int64_t m, int32_t c);
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* rowscale, int64_t m, int32_t c, float* dx,
                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
-int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* stream);
+size_t seg3d_batchnorm_workspace_bytes(int64_t m, int32_t c);
+int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* workspace, size_t workspace_bytes,
+                   void* stream);
 int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const float* gamma, const float* beta,
-                          float momentum, float* running_mean, float* running_var, float* stats, void* stream);
+                          float momentum, float* running_mean, float* running_var, float* stats, void* workspace,
+                          size_t workspace_bytes, void* stream);
 int seg3d_affine_act(const float* x, const float* res, const float* scale, const float* shift, int32_t relu,
                      int64_t m, int32_t c, float* y, void* stream);
 int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                         const float* gamma, int32_t relu, int64_t m, int32_t c, float* dx, float* dres,
-                        float* sums, void* stream);
+                        float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a7, a25, a26  torch_scatter.scatter(src, index, dim=0, reduce='mean'|'max') at

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -59,10 +59,11 @@ SIGNATURES = {
     "seg3d_layernorm_fwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _f, _i64, _i32, _p, _p, _p, _p]),
     "seg3d_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_i64, _i32]),
     "seg3d_layernorm_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, ctypes.c_size_t, _p]),
-    "seg3d_colstats": (ctypes.c_int, [_p, _i64, _i32, _p, _p]),
-    "seg3d_batchnorm_stats": (ctypes.c_int, [_p, _i64, _i32, _f, _p, _p, _f, _p, _p, _p, _p]),
+    "seg3d_batchnorm_workspace_bytes": (ctypes.c_size_t, [_i64, _i32]),
+    "seg3d_colstats": (ctypes.c_int, [_p, _i64, _i32, _p, _p, ctypes.c_size_t, _p]),
+    "seg3d_batchnorm_stats": (ctypes.c_int, [_p, _i64, _i32, _f, _p, _p, _f, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_affine_act": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
-    "seg3d_batchnorm_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
+    "seg3d_batchnorm_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_segment_reduce_fwd": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
     "seg3d_segment_reduce_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _p]),
     "seg3d_voxel_majority_labels": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),

@@ -32,14 +32,16 @@ struct BwdWs {
     __bf16 *qp, *kp, *vp, *gp;  // row-major  [mpad][heads][DHS], hi block then lo block
     __bf16 *qt, *kt, *gt;       // transposed [heads][DH][mpad],  hi block then lo block
     float *lp, *dp;             // [heads][mpad]: log2-domain LSE, delta
-    float* tau_part;            // [256] partial tau gradients (one address would serialise ~1e5 atomics)
+    float* tau_part;            // one partial tau gradient per wave of pass A, summed in a fixed order by tau_reduce
     static size_t row_bytes(int64_t mpad, int heads) {
         return align_up((size_t)mpad * heads * Geo<DH>::DHS * 2 * sizeof(__bf16), 256);
     }
     static size_t tr_bytes(int64_t mpad, int heads) { return align_up((size_t)heads * DH * mpad * 2 * sizeof(__bf16), 256); }
     static size_t f_bytes(int64_t mpad, int heads) { return align_up((size_t)mpad * heads * sizeof(float), 256); }
+    static size_t tau_count(int64_t mpad, int heads) { return (size_t)((mpad / 32 + 3) / 4 * 4) * heads; }
+    static size_t tau_bytes(int64_t mpad, int heads) { return align_up(tau_count(mpad, heads) * sizeof(float), 256); }
     static size_t total(int64_t mpad, int heads) {
-        return 4 * row_bytes(mpad, heads) + 3 * tr_bytes(mpad, heads) + 2 * f_bytes(mpad, heads) + 1024;
+        return 4 * row_bytes(mpad, heads) + 3 * tr_bytes(mpad, heads) + 2 * f_bytes(mpad, heads) + tau_bytes(mpad, heads);
     }
     BwdWs(void* base, int64_t mpad, int heads) {
         char* p = static_cast<char*>(base);
@@ -53,7 +55,7 @@ struct BwdWs {
         gt = reinterpret_cast<__bf16*>(take(tr_bytes(mpad, heads)));
         lp = reinterpret_cast<float*>(take(f_bytes(mpad, heads)));
         dp = reinterpret_cast<float*>(take(f_bytes(mpad, heads)));
-        tau_part = reinterpret_cast<float*>(take(1024));
+        tau_part = reinterpret_cast<float*>(take(tau_bytes(mpad, heads)));
     }
 };
 
@@ -241,7 +243,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __r
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (it >= n_items) return;
+    float* tau_slot = ws.tau_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (it >= n_items) {
+        if (lane == 0) *tau_slot = 0.f;
+        return;
+    }
     const int h = blockIdx.y, g = lane >> 4, c16 = lane & 15;
     const int2 item = tile_item[it];
     const int n = win_count[item.x], start = win_start[item.x];
@@ -354,16 +360,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __r
     }
     // d/dtau: s_nat = s2 * ln2 = c / tau  ->  dL/dtau = -sum(ds * s_nat) / tau   (zero while tau is clamped)
     for (int off = 32; off > 0; off >>= 1) tau_sum += __shfl_xor(tau_sum, off, SEG3D_WAVE);
-    if (lane == 0 && tau[0] > tau_min && tau_sum != 0.f) atomicAdd(&ws.tau_part[it & 255], -tau_sum * kLn2 / tau_c);
+    if (lane == 0) *tau_slot = tau[0] > tau_min ? -tau_sum * kLn2 / tau_c : 0.f;  // one plain store per wave: no atomics
 }
 
-__global__ __launch_bounds__(256) void tau_reduce(const float* __restrict__ part, float* __restrict__ dtau) {
-    float v = part[threadIdx.x];
+// dtau = sum of the per-wave partials in a fixed order
+__global__ __launch_bounds__(256) void tau_reduce(const float* __restrict__ part, int count, float* __restrict__ dtau) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) v += part[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, SEG3D_WAVE);
     __shared__ float w[4];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) dtau[0] += w[0] + w[1] + w[2] + w[3];
+    if (threadIdx.x == 0) dtau[0] = (w[0] + w[1]) + (w[2] + w[3]);
 }
 
 // ------------------------------------------------------------------ pass B: dk, dv
@@ -518,11 +526,10 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     (void)qg_item;
     (void)n_qg;
     dim3 grid((unsigned)((n_tiles + 3) / 4), (unsigned)heads);
-    if (hipMemsetAsync(ws.tau_part, 0, 1024, st) != hipSuccess) return SEG3D_ELAUNCH;
     hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, tile_item,
                        n_tiles, heads, mpad, tau, tau_min, dq, lddq);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(256), 0, st, ws.tau_part, dtau);
+    hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(256), 0, st, ws.tau_part, (int)(grid.x * 4 * grid.y), dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_kv<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0, tile_item,
                        n_tiles, heads, mpad, dk, lddk, dv, lddv);
@@ -559,7 +566,10 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
                           int32_t n_windows, int32_t heads, int32_t dh, const float* tau, float tau_min, float* dq,
                           float* dk, float* dv, int32_t lddq, int32_t lddk, int32_t lddv, float* dtau, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) return SEG3D_OK;
+    if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) {
+        if (dtau && hipMemsetAsync(dtau, 0, sizeof(float), as_stream(stream)) != hipSuccess) return SEG3D_ELAUNCH;
+        return SEG3D_OK;
+    }
     if (!q || !k || !v || !out || !dout || !lse || !tok || !win_start || !win_count || !win_tile0 || !tile_item ||
         !qg_item || m < 0 || n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !dq ||
         !dk || !dv || !dtau || !workspace)
@@ -569,7 +579,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
           reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15))
         return SEG3D_EINVAL;  // rows are gathered / stored in 16-B pieces
     if (attn_use_small(heads, dh)) {
-        if (workspace_bytes < 1024) return SEG3D_EWORKSPACE;
+        if (workspace_bytes < (size_t)n_tiles * sizeof(float)) return SEG3D_EWORKSPACE;
         return attn_small_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
                                      heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace,
                                      as_stream(stream));

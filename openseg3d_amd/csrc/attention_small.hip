@@ -270,10 +270,10 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
     for (int off = 32; off > 0; off >>= 1) tau_acc += __shfl_xor(tau_acc, off, SEG3D_WAVE);
     if ((threadIdx.x & 63) == 0) tau_red[threadIdx.x >> 6] = tau_acc;
     __syncthreads();
-    if (threadIdx.x == 0 && tau[0] > tau_min) {
+    if (threadIdx.x == 0) {  // one plain store per workgroup; tau_reduce_small adds them in a fixed order
         float t = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += tau_red[w];
-        if (t != 0.f) atomicAdd(&tau_part[blockIdx.x & 255], -t * kLn2 / tau_c);
+        tau_part[blockIdx.x] = tau[0] > tau_min ? -t * kLn2 / tau_c : 0.f;
     }
 }
 
@@ -352,13 +352,14 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_kv(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void tau_reduce_small(const float* __restrict__ part, float* __restrict__ dtau) {
-    float v = part[threadIdx.x];
+__global__ __launch_bounds__(256) void tau_reduce_small(const float* __restrict__ part, int count, float* __restrict__ dtau) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) v += part[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, SEG3D_WAVE);
     __shared__ float w[4];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) dtau[0] += w[0] + w[1] + w[2] + w[3];
+    if (threadIdx.x == 0) dtau[0] = (w[0] + w[1]) + (w[2] + w[3]);
 }
 
 template <int DH>
@@ -378,12 +379,11 @@ int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int l
                   const int32_t* win_count, const int2* tile_item, int n_tiles, int heads, const float* tau, float tau_min,
                   float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part,
                   hipStream_t st) {
-    if (hipMemsetAsync(tau_part, 0, 1024, st) != hipSuccess) return SEG3D_ELAUNCH;
     const size_t smem_q = (size_t)2 * kTile * heads * DH * sizeof(float);
     hipLaunchKernelGGL(attn_small_bwd_q<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem_q, st, q, k, v, ldq, ldk, ldv,
                        out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dq, lddq, tau_part);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(tau_reduce_small, dim3(1), dim3(256), 0, st, tau_part, dtau);
+    hipLaunchKernelGGL(tau_reduce_small, dim3(1), dim3(256), 0, st, tau_part, n_tiles, dtau);
     SEG3D_CHECK_LAUNCH();
     const size_t smem_kv = smem_q + (size_t)kTile * heads * 2 * sizeof(float);
     hipLaunchKernelGGL(attn_small_bwd_kv<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem_kv, st, q, k, v, ldq, ldk, ldv,
@@ -412,7 +412,7 @@ int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ld
                           const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
                           float* dtau, void* workspace, hipStream_t st) {
     const int2* ti = reinterpret_cast<const int2*>(tile_item);
-    float* tau_part = static_cast<float*>(workspace);  // 256 floats
+    float* tau_part = static_cast<float*>(workspace);  // n_tiles floats
     if (dh == 6)
         return run_small_bwd<6>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
                                 tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, st);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ rowscale,
                                                           int64_t m, int c, RowMap rm, float* __restrict__ dx,
                                                           float* __restrict__ part /*[gridDim.x][2][c]*/) {
-    extern __shared__ float red[];  // [2][c] block partials
+    extern __shared__ float red[];  // [4 waves x rows per wave][2][c]: one slot per row lane of the block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows_per_wave = 64 / rm.p;
     const int lr = lane / rm.p, lq = lane % rm.p;
@@ -115,8 +115,6 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
     float4 ag[ITEMS], ab[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = threadIdx.x; i < 2 * c; i += kThreads) red[i] = 0.f;
-    __syncthreads();
 
     for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave; base < m;
          base += (int64_t)gridDim.x * 4 * rows_per_wave) {
@@ -157,20 +155,25 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
             }
         }
     }
-    // block partials: LDS float atomics (few per thread), then one plain store per channel per block; ln_bwd_reduce
-    // sums the blocks in a fixed order (no contended global atomics, no memset, deterministic)
+    // block partials: every row lane parks its sums in its own LDS slot, the slots are added in a fixed order and each
+    // channel gets one plain store per block; ln_bwd_reduce then sums the blocks in a fixed order (no atomics of any
+    // kind, no memset: bit-identical from run to run)
+    const int slots = 4 * rows_per_wave;
+    float* mine = red + (size_t)(wave * rows_per_wave + lr) * 2 * c;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int q = lq + i * rm.p;
         if (q < rm.quads) {
-            atomicAdd(&red[4 * q + 0], ag[i].x); atomicAdd(&red[4 * q + 1], ag[i].y);
-            atomicAdd(&red[4 * q + 2], ag[i].z); atomicAdd(&red[4 * q + 3], ag[i].w);
-            atomicAdd(&red[c + 4 * q + 0], ab[i].x); atomicAdd(&red[c + 4 * q + 1], ab[i].y);
-            atomicAdd(&red[c + 4 * q + 2], ab[i].z); atomicAdd(&red[c + 4 * q + 3], ab[i].w);
+            *reinterpret_cast<float4*>(mine + 4 * q) = ag[i];
+            *reinterpret_cast<float4*>(mine + c + 4 * q) = ab[i];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * c; i += kThreads) part[(int64_t)blockIdx.x * 2 * c + i] = red[i];
+    for (int i = threadIdx.x; i < 2 * c; i += kThreads) {
+        float t = red[i];
+        for (int l = 1; l < slots; ++l) t += red[(size_t)l * 2 * c + i];
+        part[(int64_t)blockIdx.x * 2 * c + i] = t;
+    }
 }
 
 // dgamma[i] = sum_b part[b][i], dbeta[i] = sum_b part[b][c + i]; 32 block lanes per column, combined in lane order
@@ -201,13 +204,11 @@ template <int MODE>
 __global__ __launch_bounds__(kThreads) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const float* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int relu, int64_t m, int c,
-                                                              float* __restrict__ out /*[2][c]*/) {
-    extern __shared__ float red[];  // [2][c]
+                                                              float* __restrict__ part /*[gridDim.x][2][c]*/) {
+    extern __shared__ float red[];  // [row lanes][2][c] (<= 8 KiB)
     const int quads = c / 4;
     const int lanes = kThreads / quads;  // row lanes per block
     const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
-    for (int i = threadIdx.x; i < 2 * c; i += kThreads) red[i] = 0.f;
-    __syncthreads();
     if (rl < lanes) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         float4 p0 = a, p1 = a;
@@ -234,13 +235,39 @@ __global__ __launch_bounds__(kThreads) void col_reduce_kernel(const float* __res
                 b.z += g.z * (xv.z - p0.z) * p1.z; b.w += g.w * (xv.w - p0.w) * p1.w;
             }
         }
-        atomicAdd(&red[4 * q + 0], a.x); atomicAdd(&red[4 * q + 1], a.y);
-        atomicAdd(&red[4 * q + 2], a.z); atomicAdd(&red[4 * q + 3], a.w);
-        atomicAdd(&red[c + 4 * q + 0], b.x); atomicAdd(&red[c + 4 * q + 1], b.y);
-        atomicAdd(&red[c + 4 * q + 2], b.z); atomicAdd(&red[c + 4 * q + 3], b.w);
+        *reinterpret_cast<float4*>(red + (size_t)rl * 2 * c + 4 * q) = a;
+        *reinterpret_cast<float4*>(red + (size_t)rl * 2 * c + c + 4 * q) = b;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * c; i += kThreads) atomicAdd(&out[i], red[i]);
+    // fixed-order sum over the row lanes, one plain store per channel per block: no atomics anywhere
+    for (int i = threadIdx.x; i < 2 * c; i += kThreads) {
+        float t = red[i];
+        for (int l = 1; l < lanes; ++l) t += red[(size_t)l * 2 * c + i];
+        part[(size_t)blockIdx.x * 2 * c + i] = t;
+    }
+}
+
+// sums[i] = sum over blocks of part[b][i], i < 2c, in a fixed order (32 channels x 32 block lanes per workgroup)
+__device__ __forceinline__ float col_partial_sum(const float* __restrict__ part, int nblocks, int c2, int i, float (*red)[33]) {
+    const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
+    float s = 0.f;
+    if (i < c2)
+        for (int b = q; b < nblocks; b += 32) s += part[(int64_t)b * c2 + i];
+    red[q][col] = s;
+    __syncthreads();
+    float t = red[0][col];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) t += red[k][col];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void col_sums_finish(const float* __restrict__ part, int nblocks, int c,
+                                                        float* __restrict__ sums /*[2][c]*/) {
+    __shared__ float red[32][33];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31);
+    const float t = col_partial_sum(part, nblocks, 2 * c, i, red);
+    if ((threadIdx.x >> 5) == 0 && i < 2 * c) sums[i] = t;
 }
 
 // y = act(x * scale + shift (+ res))
@@ -296,17 +323,24 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
     }
 }
 
-// batch statistics -> everything the forward / backward passes and the running buffers need, one thread per channel
-__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const float* __restrict__ x, int64_t m, int c, float eps,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float momentum, float* __restrict__ running_mean,
-                                                               float* __restrict__ running_var, float* __restrict__ stats) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= c) return;
+// batch statistics -> everything the forward / backward passes and the running buffers need: the block partials are
+// summed in a fixed order (32 channels x 32 block lanes per workgroup), then one thread per channel finishes
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                           int nblocks, int64_t m, int c, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float momentum, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ stats) {
+    __shared__ float red[32][33];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31);
+    const float s1 = col_partial_sum(part, nblocks, 2 * c, i < c ? i : 2 * c, red);
+    const float s2 = col_partial_sum(part, nblocks, 2 * c, i < c ? c + i : 2 * c, red);
+    if ((threadIdx.x >> 5) != 0 || i >= c) return;
+    stats[i] = s1;
+    stats[c + i] = s2;
     const float inv_m = 1.0f / (float)m;
-    const float d = stats[i] * inv_m;              // mean of (x - x[0])
+    const float d = s1 * inv_m;              // mean of (x - x[0])
     const float mean = x[i] + d;
-    const float var = fmaxf(stats[c + i] * inv_m - d * d, 0.0f);  // biased
+    const float var = fmaxf(s2 * inv_m - d * d, 0.0f);  // biased
     const float rstd = 1.0f / sqrtf(var + eps);
     const float scale = gamma[i] * rstd;
     stats[2 * c + i] = mean;
@@ -319,6 +353,9 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const float* __re
         running_var[i] = running_var[i] * (1.0f - momentum) + unbiased * momentum;
     }
 }
+
+constexpr int kColMaxBlocks = 1024;
+constexpr size_t kColSmem = 8192;
 
 inline unsigned blocks_for(int64_t work_items, int per_block) {
     int64_t b = ceil_div64(work_items, per_block);
@@ -368,7 +405,7 @@ int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
         const RowMap rm = row_map(c);
         nb = blocks_for(m, 4 * (64 / rm.p) * 4);  // ~4 row batches per wave
         if (nb > (unsigned)kLnBwdMaxBlocks) nb = kLnBwdMaxBlocks;
-        const size_t smem = (size_t)2 * c * sizeof(float);
+        const size_t smem = (size_t)4 * (64 / rm.p) * 2 * c * sizeof(float);
         if (rm.items == 1)
             hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c,
                                rm, dx, part);
@@ -383,28 +420,45 @@ int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
     return SEG3D_OK;
 }
 
-int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums /*[2][c]: sum(x-x0), sum((x-x0)^2)*/, void* stream) {
-    if (m < 0 || bad_c(c) || !sums) return SEG3D_EINVAL;
-    hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (m == 0) return SEG3D_OK;
-    if (!x) return SEG3D_EINVAL;
+size_t seg3d_batchnorm_workspace_bytes(int64_t m, int32_t c) {
+    if (m < 0 || bad_c(c)) return 0;
+    return (size_t)kColMaxBlocks * 2 * c * sizeof(float);
+}
+
+static unsigned col_blocks(int64_t m, int c) {
     const int lanes = kThreads / (c / 4);
     unsigned nb = blocks_for(m, lanes * 16);
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(kThreads), (size_t)2 * c * sizeof(float), st, x, nullptr,
-                       nullptr, nullptr, nullptr, 0, m, c, sums);
+    return nb > (unsigned)kColMaxBlocks ? (unsigned)kColMaxBlocks : nb;
+}
+
+int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums /*[2][c]: sum(x-x0), sum((x-x0)^2)*/,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (m <= 0 || bad_c(c) || !sums || !x) return SEG3D_EINVAL;
+    if (!workspace || workspace_bytes < seg3d_batchnorm_workspace_bytes(m, c)) return SEG3D_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const unsigned nb = col_blocks(m, c);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(kThreads), kColSmem, st, x, nullptr, nullptr, nullptr, nullptr, 0, m,
+                       c, part);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(col_sums_finish, dim3((unsigned)((2 * c + 31) / 32)), dim3(1024), 0, st, part, (int)nb, c, sums);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
 
 int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const float* gamma, const float* beta,
-                          float momentum, float* running_mean, float* running_var, float* stats /*[6][c]*/, void* stream) {
+                          float momentum, float* running_mean, float* running_var, float* stats /*[6][c]*/,
+                          void* workspace, size_t workspace_bytes, void* stream) {
     if (m <= 0 || bad_c(c) || !x || !gamma || !beta || !stats || (running_mean && !running_var)) return SEG3D_EINVAL;
-    const int rc = seg3d_colstats(x, m, c, stats, stream);
-    if (rc != SEG3D_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + kThreads - 1) / kThreads)), dim3(kThreads), 0, as_stream(stream),
-                       x, m, c, eps, gamma, beta, momentum, running_mean, running_var, stats);
+    if (!workspace || workspace_bytes < seg3d_batchnorm_workspace_bytes(m, c)) return SEG3D_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const unsigned nb = col_blocks(m, c);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(kThreads), kColSmem, st, x, nullptr, nullptr, nullptr, nullptr, 0, m,
+                       c, part);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 31) / 32)), dim3(1024), 0, st, x, part, (int)nb, m, c, eps, gamma,
+                       beta, momentum, running_mean, running_var, stats);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -423,17 +477,16 @@ int seg3d_affine_act(const float* x, const float* res, const float* scale, const
 
 int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                         const float* gamma, int32_t relu, int64_t m, int32_t c, float* dx, float* dres,
-                        float* sums /*[2][c] out: dbeta, dgamma*/, void* stream) {
-    if (m < 0 || bad_c(c) || !sums) return SEG3D_EINVAL;
-    hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (m == 0) return SEG3D_OK;
+                        float* sums /*[2][c] out: dbeta, dgamma*/, void* workspace, size_t workspace_bytes, void* stream) {
+    if (m <= 0 || bad_c(c) || !sums) return SEG3D_EINVAL;
+    if (!workspace || workspace_bytes < seg3d_batchnorm_workspace_bytes(m, c)) return SEG3D_EWORKSPACE;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || (relu && !y)) return SEG3D_EINVAL;
-    const int lanes = kThreads / (c / 4);
-    unsigned nb = blocks_for(m, lanes * 16);
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(nb), dim3(kThreads), (size_t)2 * c * sizeof(float), st, x, dy, y, mean,
-                       rstd, relu, m, c, sums);
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const unsigned nb = col_blocks(m, c);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(nb), dim3(kThreads), kColSmem, st, x, dy, y, mean, rstd, relu, m, c, part);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(col_sums_finish, dim3((unsigned)((2 * c + 31) / 32)), dim3(1024), 0, st, part, (int)nb, c, sums);
     SEG3D_CHECK_LAUNCH();
     const int64_t tq = m * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(tq, kThreads * 4)), dim3(kThreads), 0, st, dy, y, x, mean, rstd,

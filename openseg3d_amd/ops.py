@@ -538,8 +538,10 @@ class _BatchNormActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, c)
+        ws = _workspace(ws_bytes, x.device)
         _lib.call("seg3d_batchnorm_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), int(ctx.relu),
-                  m, c, _ptr(dx), _ptr(dres), _ptr(sums), _stream())
+                  m, c, _ptr(dx), _ptr(dres), _ptr(sums), _ptr(ws), ws_bytes, _stream())
         return dx, dres, sums[1], sums[0], None, None, None, None, None
 
 
@@ -565,9 +567,11 @@ def batch_norm_act(x, bn, relu=True, res=None):
             if track:
                 bn.num_batches_tracked += 1
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, c)
+            ws = _workspace(ws_bytes, x.device)
             _lib.call("seg3d_batchnorm_stats", _ptr(xc), m, c, float(bn.eps), _ptr(bn.weight), _ptr(bn.bias), float(mom),
                       _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None, _ptr(stats),
-                      _stream())
+                      _ptr(ws), ws_bytes, _stream())
         return _BatchNormActFn.apply(xc, res, bn.weight, bn.bias, stats[2], stats[3], stats[4], stats[5], bool(relu))
     with torch.no_grad():
         scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
@@ -656,7 +660,7 @@ class _WindowAttnFn(torch.autograd.Function):
         dev = v.device
         dout = _f32c(dout)
         dq, dk, dv = (torch.empty((m, c), dtype=torch.float32, device=dev) for _ in range(3))
-        dtau = torch.zeros((1,), dtype=torch.float32, device=dev)
+        dtau = torch.empty((1,), dtype=torch.float32, device=dev)  # written (not accumulated) by the kernels
         ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, c // heads), dev)
         _lib.call("seg3d_window_attn_bwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
                   _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count),
@@ -697,7 +701,7 @@ class _WindowAttnPackedFn(torch.autograd.Function):
         dout = _f32c(dout)
         dqk = torch.empty((m, 2 * c), dtype=torch.float32, device=dev)
         dv = torch.empty((m, c), dtype=torch.float32, device=dev)
-        dtau = torch.zeros((1,), dtype=torch.float32, device=dev)
+        dtau = torch.empty((1,), dtype=torch.float32, device=dev)  # written (not accumulated) by the kernels
         ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, c // heads), dev)
         kp = ctypes.c_void_p(qk.data_ptr() + 4 * c)
         dkp = ctypes.c_void_p(dqk.data_ptr() + 4 * c)

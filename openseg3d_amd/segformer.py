@@ -13,6 +13,7 @@ window CSRs, point->voxel CSR) are built once per batch and shared by all layers
 Scope: all three shipped configs -- single sweep (cartesian / cylinder) and multi-sweep with optional
 image-feature fusion (DeepFusionBlock over seg3d_knn_query).
 """
+import os
 from collections import OrderedDict
 from functools import partial
 
@@ -22,6 +23,11 @@ import torch.nn as nn
 from . import ops
 from . import spconv
 from .swformer import SparseWindowPartitionLayer, SWFormerBlock
+
+
+# Build every index structure of a forward before its first feature kernel (PointTransformer.prepare); 0 restores the
+# lazy per-stage order for A/B timing.
+PLAN_FIRST = os.environ.get("SEG3D_PLAN_FIRST", "1") != "0"
 
 
 def replace_feature(out, new_features):
@@ -169,9 +175,27 @@ class PointTransformer(nn.Module):
         self.aux_voxel_classifier = nn.Sequential(RowLinear(384, num_classes, bias=False))
         self.voxel_classifier = nn.Sequential(RowLinear(output_channels, num_classes, bias=False))
 
+    def prepare(self, batch_dict):
+        """Index plan of the whole backbone -- site levels, rulebooks, row orders, window plans of the four stages --
+        built before any feature kernel is queued.  All 7 host read-backs of a forward (3 strided levels, 4 window
+        plans) happen here, while only short index kernels are in flight; afterwards the feature pipeline (forward,
+        loss, backward) is enqueued without a single wait, so the host runs ahead of the GPU instead of draining the
+        queue once per stage."""
+        level = spconv.SiteLevel(batch_dict["voxel_coords"].int(), self.sparse_shape, batch_dict["batch_size"])
+        batch_dict["site_level"] = level
+        widths = (48, 96, 192, 384)
+        for k in range(4):
+            level.subm()
+            getattr(self, f"swformer_block{k + 1}")[0].plan_level(level, widths[k])
+            if k < 3:
+                level.parity_order()
+                level = level.down()[0]
+        return batch_dict
+
     def forward(self, batch_dict):
         x = spconv.SparseConvTensor(features=batch_dict["voxel_features"], indices=batch_dict["voxel_coords"].int(),
-                                    spatial_shape=self.sparse_shape, batch_size=batch_dict["batch_size"])
+                                    spatial_shape=self.sparse_shape, batch_size=batch_dict["batch_size"],
+                                    _level=batch_dict.get("site_level"))
         x1 = self.conv_input(x)
         x1 = x1.replace_feature(self.swformer_block1(x1))
         x2 = self.conv_down1(x1)
@@ -313,6 +337,8 @@ class Segformer(nn.Module):
         seg = batch_dict.get("point_voxel_index")
         if seg is None:
             seg = ops.SegmentIndex(ids, n_voxels)
+        if PLAN_FIRST:
+            self.point_transformer.prepare(batch_dict)
 
         if self.use_multi_sweeps:
             cur = points[:, 3] == 0  # rows of the current sweep: time lag column == 0 (segformer.py:98)

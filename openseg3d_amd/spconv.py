@@ -39,6 +39,7 @@ class SiteLevel:
         self._down = None
         self._parity = None
         self._offsets = False
+        self.window_plans = {}  # SparseWindowPartitionLayer -> WindowPlan of this level (built once per forward)
 
     def sample_offsets(self):
         """Cumulative row count per sample as python ints when every sample's rows are contiguous and in sample

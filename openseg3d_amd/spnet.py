@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from . import segformer as segformer_mod
 from . import spconv
 from .segformer import (ConvBnAct, DeepFusionBlock, FlattenSELayer, FusedMLP, RowLinear, UpBlock, VFE, _bn_mlp,
                         conv_module)
@@ -152,9 +153,25 @@ class SparseUnet(nn.Module):
         self.aux_voxel_classifier = nn.Sequential(RowLinear(256, num_classes, bias=False))
         self.voxel_classifier = nn.Sequential(RowLinear(output_channels, num_classes, bias=False))
 
+    def prepare(self, batch_dict):
+        """All site levels, rulebooks, row orders and per-sample row offsets before the first feature kernel: the three
+        host read-backs (strided level sizes) happen while only index kernels are in flight (see
+        segformer.PointTransformer.prepare)."""
+        level = spconv.SiteLevel(batch_dict["voxel_coords"].int(), self.sparse_shape, batch_dict["batch_size"])
+        batch_dict["site_level"] = level
+        for k in range(4):
+            level.subm()
+            if k >= 2:
+                level.sample_offsets()  # squeeze-excite of conv3 / conv4, OCR
+            if k < 3:
+                level.parity_order()
+                level = level.down()[0]
+        return batch_dict
+
     def forward(self, batch_dict):
         coords = batch_dict["voxel_coords"]
-        x = spconv.SparseConvTensor(batch_dict["voxel_features"], coords.int(), self.sparse_shape, batch_dict["batch_size"])
+        x = spconv.SparseConvTensor(batch_dict["voxel_features"], coords.int(), self.sparse_shape, batch_dict["batch_size"],
+                                    _level=batch_dict.get("site_level"))
         x = self.conv_input(x)
         x1 = self.conv1(x)
         x2 = self.conv2(x1)
@@ -224,6 +241,8 @@ class SPNet(nn.Module):
         seg = batch_dict.get("point_voxel_index")
         if seg is None:
             seg = ops.SegmentIndex(ids, n_voxels)
+        if segformer_mod.PLAN_FIRST:
+            self.voxel_encoder.prepare(batch_dict)
         if self.use_multi_sweeps:
             cur_rows = torch.nonzero(points[:, 3] == 0).view(-1)  # spnet.py:97
             cur_points, cur_ids, cur_seg = points[cur_rows], seg.ids[cur_rows], None

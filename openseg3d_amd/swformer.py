@@ -96,9 +96,17 @@ class SparseWindowPartitionLayer(nn.Module):
                     "unsupported (it breaks replace_feature in the reference too, SURVEY.md 8 quirk 1)")
         return WindowPlan(index, pos)
 
+    def plan_level(self, level, feat_dim):
+        """The plan of a spconv.SiteLevel, cached on the level: the backbone asks for every stage's plan up front
+        (segformer.PointTransformer.prepare) so that the host syncs happen before any feature kernel is queued."""
+        plan = level.window_plans.get(self)
+        if plan is None:
+            plan = level.window_plans[self] = self.plan(level.coords, level.batch_size, feat_dim)
+        return plan
+
     def forward(self, x):
         feats = x.features
-        return {"voxel_features": feats, "plan": self.plan(x.indices, x.batch_size, feats.shape[1])}
+        return {"voxel_features": feats, "plan": self.plan_level(x.level, feats.shape[1])}
 
 
 class CosineMultiheadAttention(nn.Module):

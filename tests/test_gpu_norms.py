@@ -85,8 +85,8 @@ def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
     ref = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
     ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
     if relu:
-        # keep every pre-activation away from the ReLU kink: the GPU sums the batch statistics in a run-dependent
-        # order, so an element within rounding of zero may take the other branch and move dx / dgamma by O(1)
+        # keep every pre-activation away from the ReLU kink: the fp32 batch statistics differ from the fp64 reference by
+        # rounding, so an element within rounding of zero may take the other branch and move dx / dgamma by O(1)
         for _ in range(4):
             with torch.no_grad():
                 pre = torch.nn.functional.batch_norm(x.double(), None, None, ref.weight, ref.bias, True, 0.0, 1e-3)

@@ -48,6 +48,40 @@ def test_training_step_reaches_every_parameter():
     assert int(bn.num_batches_tracked) == 3 and torch.isfinite(bn.running_var).all()
 
 
+@pytest.mark.parametrize("segmentor", ["segformer", "spnet"])
+def test_training_step_is_bit_reproducible(segmentor):
+    """No kernel on the single-sweep training path accumulates with atomics (weight gradients, LayerNorm / BatchNorm sums,
+    tau gradient, losses all reduce per-block partials in a fixed order): the same step from the same state yields the
+    same loss and the same gradients bit for bit, DropPath masks included once the generator is re-seeded."""
+    from openseg3d_amd import batch as B, config, losses, ops, scene, segformer
+    dev = torch.device("cuda:0")
+    cfg = config.default_cfg()
+    cfg.MODEL.SEGMENTOR = segmentor
+    ds = config.DatasetSpec(cfg)
+    torch.manual_seed(1)
+    model = segformer.build_segmentor(cfg, ds).to(dev).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    crit = losses.build_criterion(cfg, ds)
+    samples = [scene.make_small_scene(17, 9000, extent=10.0), scene.make_small_scene(18, 5000, extent=6.0)]
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(123)
+        b = B.make_batch(samples, ds.voxel_size, ds.point_cloud_range)
+        n = b["points"].shape[0]
+        b["point_labels"] = (torch.arange(n, device=dev) * 5 % 22).long()
+        b["voxel_labels"] = ops.prepare_voxel_labels(b["point_voxel_ids"], b["point_labels"].to(torch.uint8),
+                                                     b["voxel_coords"].shape[0]).long()
+        res = model(b)
+        loss = losses.compute_loss(res, b, crit, cfg)
+        loss.backward()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    differing = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
+    assert not differing, differing[:8]
+
+
 def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--scenes", "1",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)

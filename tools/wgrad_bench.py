@@ -6,11 +6,14 @@ import ctypes
 import torch
 from openseg3d_amd import _lib, ops
 
-SHAPES = [(121168, 96, 96), (121168, 96, 192), (121168, 192, 96), (58453, 192, 192), (58453, 192, 384),
-          (58453, 384, 192), (19483, 384, 384), (19483, 384, 768), (19483, 768, 384), (6943, 768, 768),
-          (174633, 64, 64), (174633, 64, 128)]
+# (rows, cin, cout, calls per training step): per encoder layer qk C->2C, v C->C, out C->C, mlp C->2C->C
+SHAPES = []
+for m, c, depth in ((108690, 48, 3), (121168, 96, 4), (58453, 192, 8), (19483, 384, 3)):
+    SHAPES += [(m, c, 2 * c, 2 * depth), (m, c, c, 2 * depth), (m, 2 * c, c, depth)]
+SHAPES += [(174633, 64, 128, 1), (174633, 128, 256, 1), (174633, 256, 64, 1), (174633, 96, 256, 1), (174633, 256, 128, 1)]
 dev = torch.device("cuda:0")
-for m, cin, cout in SHAPES:
+total = 0.0
+for m, cin, cout, calls in SHAPES:
     x = torch.randn(m, cin, device=dev)
     dy = torch.randn(m, cout, device=dev)
     dw = torch.empty(cout, cin, device=dev)
@@ -30,4 +33,6 @@ for m, cin, cout in SHAPES:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     gb = m * (cin + cout) * 4 / 1e9
-    print(f"m={m:7d} {cin:4d}->{cout:4d}: {us:7.1f} us  {gb / us * 1e6:7.0f} GB/s algorithmic  ws {nb / 1e6:.1f} MB", flush=True)
+    total += us * calls
+    print(f"m={m:7d} {cin:4d}->{cout:4d}: {us:7.1f} us x{calls:2d}  {gb / us * 1e6:7.0f} GB/s algorithmic  ws {nb / 1e6:.1f} MB", flush=True)
+print(f"sum over one training step: {total / 1e3:.2f} ms")
