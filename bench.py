@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
 ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
+# single-rank rehearsal of the multi-GPU path (RCCL process group, DDP wrapper, barriers) on a one-GPU box:
+# python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 with SEG3D_BENCH_DIST=1
+DIST_REHEARSAL = os.environ.get("SEG3D_BENCH_DIST", "0") == "1" and "RANK" in os.environ
 
 
 def parse():
@@ -57,7 +60,7 @@ def setup_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or DIST_REHEARSAL:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")  # RCCL over xGMI
@@ -66,7 +69,7 @@ def setup_dist(args):
 
 
 def barrier(world):
-    if world > 1:
+    if world > 1 or DIST_REHEARSAL:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
@@ -223,7 +226,7 @@ def main():
     train = args.mode == "fwdbwd"
     opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)  # configs/waymo_one_sweep.yaml
     net = model
-    if train and world > 1:
+    if train and (world > 1 or DIST_REHEARSAL):
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True)
     labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
@@ -307,7 +310,7 @@ def main():
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
             json.dump(per_layer, f, indent=1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or DIST_REHEARSAL:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

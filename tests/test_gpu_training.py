@@ -99,3 +99,19 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches"] == 20 and d["attention_roofline"]["layers"] == sum(refcfg.DEPTHS)
     assert d["fwd_only"]["value"] > d["value"]
+
+
+def test_bench_distributed_path_single_rank_rehearsal():
+    """The N > 1 code path of bench.py (RCCL process group, DistributedDataParallel around the model with
+    find_unused_parameters=False, barriers, rank-0 reporting) driven by torch.distributed.run with one rank: everything
+    but the cross-GPU traffic itself.  The driver launches the same command line with --nproc-per-node N."""
+    env = dict(os.environ, SEG3D_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                          "--steps", "2", "--warmup", "1", "--scenes", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
