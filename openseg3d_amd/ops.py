@@ -746,7 +746,9 @@ class _AttnInProjFn(torch.autograd.Function):
         dqk, dv = _f32c(dqk), _f32c(dv)
         dx = dpos = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            d_xp = _linear_apply(dqk, _linear_pack(w_in[: 2 * c], 1), None, 2 * c, c)
+            # an enclosing layer function may hand over the residual path's gradient: it rides in the same epilogue
+            extra = None if ctx.needs_input_grad[1] else getattr(ctx, "dx_addend", None)
+            d_xp = _linear_apply(dqk, _linear_pack(w_in[: 2 * c], 1), None, 2 * c, c, addend=extra)
             if ctx.needs_input_grad[1]:
                 dpos = d_xp
             if ctx.needs_input_grad[0]:
@@ -781,6 +783,127 @@ def window_attention(q, k, v, tau, tau_min, heads, wi):
         if t.dtype != torch.float32 or t.stride(1) != 1:
             raise _lib.Seg3dError("q/k/v must be float32 with a contiguous last dimension")
     return _WindowAttnFn.apply(q, k, v, tau, tau_min, heads, wi)
+
+
+def _linear_act(x, packed, bias, cin, cout, mode, aux_in=None, want_pre=False):
+    """seg3d_linear_fwd_act: mode 1 -> (gelu(x W^T + b), pre-activation or None); mode 2 -> (x W^T) * gelu'(aux_in)."""
+    y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if (mode == 1 and want_pre) else None
+    _lib.call("seg3d_linear_fwd_act", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), cin, cout, int(mode), _ptr(aux_in),
+              _ptr(pre), _ptr(y), _stream())
+    return (y, pre) if mode == 1 else y
+
+
+def _linear_wgrad(x, dy, cin, cout, want_db=True):
+    """(dW [cout, cin], db [cout] or None) of y = x W^T + b from the tall-skinny split-bf16 kernel (deterministic)."""
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=dy.device) if want_db else None
+    ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
+    ws = _workspace(ws_bytes, dy.device)
+    _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream())
+    return dw, db
+
+
+class _LinearGeluFn(torch.autograd.Function):
+    """gelu(x W^T + b) with the activation in the GEMM epilogue (forward) and its derivative applied to the incoming
+    gradient in one elementwise pass (backward); used on paths that do not go through _EncoderLayerFn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _f32c(x)
+        cout, cin = weight.shape
+        keep = any(ctx.needs_input_grad)  # forward runs with grad mode off: ask the node, not torch.is_grad_enabled()
+        y, pre = _linear_act(x, _linear_pack(weight, 0), None if bias is None else _f32c(bias), cin, cout, 1, want_pre=keep)
+        ctx.save_for_backward(x, weight, pre)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, pre = ctx.saved_tensors
+        cout, cin = weight.shape
+        dh = torch.ops.aten.gelu_backward(_f32c(dy), pre)
+        dx = _linear_apply(dh, _linear_pack(weight, 1), None, cout, cin) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw, db = _linear_wgrad(x, dh, cin, cout, ctx.has_bias)
+        return dx, dw, db
+
+
+def linear_gelu(x, weight, bias):
+    """F.gelu(F.linear(x, weight, bias)) (exact erf form) in one kernel when the shape fits the MFMA tiles."""
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0
+            and CONV_PRECISION == "bf16x3" and (weight.shape[1] % 16 == 0 or not torch.is_grad_enabled())):
+        return _LinearGeluFn.apply(x, weight, bias)
+    return torch.nn.functional.gelu(linear(x, weight, bias))
+
+
+class _Ctx:
+    """Stand-in for autograd's ctx when an enclosing Function drives another Function's forward / backward."""
+
+    def __init__(self, *needs):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _EncoderLayerFn(torch.autograd.Function):
+    """One post-norm encoder layer (point_transformer_layer.py:289-298) as a single autograd node:
+        a  = out_proj(window_attention(in_proj(x, pos)))          x1 = x  + s1 * LN1(a)
+        m  = fc2(gelu(fc1(x1)))                                   x2 = x1 + s2 * LN2(m)
+    Same kernels as the composed modules.  What the single node buys: the two residual-path gradients are added in the
+    epilogue of the branch's last input-gradient GEMM (no autograd accumulation adds), the GELU lives in the fc1 / fc2
+    GEMM epilogues both ways (no elementwise passes over [rows, 2C]), and the engine walks 1 node instead of 9."""
+
+    @staticmethod
+    def forward(ctx, x, pos, w_in, b_in, tau, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, meta):
+        heads, tau_min, wi, eps1, eps2, s1, s2 = meta
+        x = _f32c(x)
+        c = x.shape[1]
+        c_in = _Ctx(True, False, True, True)
+        qk, v = _AttnInProjFn.forward(c_in, x, pos, w_in, b_in)
+        c_at = _Ctx(True, True, True, False, False, False)
+        o = _WindowAttnPackedFn.forward(c_at, qk, v, tau, tau_min, heads, wi)
+        a = _linear_apply(o, _linear_pack(w_out, 0), b_out, c, c)
+        c_n1 = _Ctx(True, True, True, True, False, False)
+        x1 = _LayerNormResidualFn.forward(c_n1, a, x, g1, be1, eps1, s1)
+        hid = w1.shape[0]
+        g, h = _linear_act(x1, _linear_pack(w1, 0), b1, c, hid, 1, want_pre=True)
+        m = _linear_apply(g, _linear_pack(w2, 0), b2, hid, c)
+        c_n2 = _Ctx(True, True, True, True, False, False)
+        x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
+        ctx.parts = (c_in, c_at, c_n1, c_n2)
+        ctx.save_for_backward(o, x1, h, g, w_out, w1, w2)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        c_in, c_at, c_n1, c_n2 = ctx.parts
+        o, x1, h, g, w_out, w1, w2 = ctx.saved_tensors
+        dx2 = _f32c(dx2)
+        c, hid = x1.shape[1], w1.shape[0]
+        # MLP branch: LN2 -> fc2 (x gelu') -> fc1, the residual gradient dx2 joins in fc1's epilogue
+        dm, _, dg2, dbe2, _, _ = _LayerNormResidualFn.backward(c_n2, dx2)
+        dh = _linear_act(dm, _linear_pack(w2, 1), None, c, hid, 2, aux_in=h)
+        dw2, db2 = _linear_wgrad(g, dm, hid, c)
+        d_x1 = _linear_apply(dh, _linear_pack(w1, 1), None, hid, c, addend=dx2)
+        dw1, db1 = _linear_wgrad(x1, dh, c, hid)
+        # attention branch: LN1 -> out_proj -> attention -> in_proj, d_x1 joins in the in-projection's epilogue
+        da, _, dg1, dbe1, _, _ = _LayerNormResidualFn.backward(c_n1, d_x1)
+        do = _linear_apply(da, _linear_pack(w_out, 1), None, c, c)
+        dw_out, db_out = _linear_wgrad(o, da, c, c)
+        dqk, dv, dtau = _WindowAttnPackedFn.backward(c_at, do)[:3]
+        c_in.dx_addend = d_x1
+        dx, _, dw_in, db_in = _AttnInProjFn.backward(c_in, dqk, dv)
+        ctx.parts = None
+        return dx, None, dw_in, db_in, dtau, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, None
+
+
+def encoder_layer_fits(x, c, hid, heads):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and c % 16 == 0 and hid % 16 == 0 and c <= 512
+            and c % heads == 0 and CONV_PRECISION == "bf16x3")
 
 
 # ------------------------------------------------------------------------------------------ a7/a24-a26

@@ -17,8 +17,10 @@ What changed underneath (MI355X-first):
 Dense projections / MLP / LayerNorm stay on torch (rocBLAS/hipBLASLt GEMMs).
 """
 import math
+import os
 
 import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -149,7 +151,7 @@ class MLP(nn.Module):
         self.drop = drop
 
     def forward(self, x):
-        x = F.gelu(ops.linear(x, self.fc1.weight, self.fc1.bias))
+        x = ops.linear_gelu(x, self.fc1.weight, self.fc1.bias)  # GELU in the GEMM epilogue
         if self.drop and self.training:
             x = F.dropout(x, self.drop)
         x = ops.linear(x, self.fc2.weight, self.fc2.bias)
@@ -174,6 +176,10 @@ def drop_path(x, p, training):
     return x * drop_path_scale(x, p).reshape((x.shape[0],) + (1,) * (x.dim() - 1))
 
 
+# One autograd node per encoder layer in training (ops._EncoderLayerFn); 0 = compose the layer from its modules.
+FUSED_LAYER = os.environ.get("SEG3D_FUSED_LAYER", "1") != "0"
+
+
 class EncoderLayer(nn.Module):
     """Post-norm encoder layer: x + DP(LN1(attn(x))), then + DP(LN2(mlp(.))) (point_transformer_layer.py:289-298)."""
 
@@ -186,6 +192,18 @@ class EncoderLayer(nn.Module):
         self.drop_path_rate = float(drop_path_rate)
 
     def forward(self, x, pos, wi):
+        at, mlp = self.win_attn.self_attn, self.mlp
+        if (FUSED_LAYER and torch.is_grad_enabled() and x.requires_grad and not mlp.drop and at.in_proj_bias is not None
+                and ops.encoder_layer_fits(x, at.embed_dim, mlp.fc1.out_features, at.num_heads)):
+            # training: the whole layer is one autograd node (ops._EncoderLayerFn)
+            drop = self.training and self.drop_path_rate > 0.0
+            s1 = drop_path_scale(x, self.drop_path_rate) if drop else None
+            s2 = drop_path_scale(x, self.drop_path_rate) if drop else None
+            meta = (at.num_heads, at.tau_min, wi, self.norm1.eps, self.norm2.eps, s1, s2)
+            return ops._EncoderLayerFn.apply(x, pos, at.in_proj_weight, at.in_proj_bias, at.tau, at.out_proj.weight,
+                                             at.out_proj.bias, self.norm1.weight, self.norm1.bias, mlp.fc1.weight,
+                                             mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, self.norm2.weight,
+                                             self.norm2.bias, meta)
         a = self.win_attn(x, pos, wi)
         if self.drop_path_rate == 0.0 or not self.training:  # fused residual + LayerNorm
             x = ops.layer_norm_residual(a, x, self.norm1)

@@ -1,0 +1,67 @@
+"""The single-node encoder layer (ops._EncoderLayerFn) and the GELU GEMM epilogues against the composed modules / torch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,cin,cout", [(5000, 48, 96), (777, 192, 384), (1, 96, 192)])
+def test_linear_gelu_epilogues_match_torch(m, cin, cout):
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m + cin)
+    x = torch.randn(m, cin)
+    w = torch.randn(cout, cin) / cin ** 0.5
+    b = torch.randn(cout) * 0.1
+    g = torch.randn(m, cout)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.gelu(torch.nn.functional.linear(xr, wr, br))
+    yr.backward(g.double())
+    xg, wg, bg = (t.to(dev).requires_grad_() for t in (x, w, b))
+    y = ops.linear_gelu(xg, wg, bg)
+    assert "LinearGelu" in type(y.grad_fn).__name__
+    y.backward(g.to(dev))
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-4
+    for got, ref in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    # mode 2 of seg3d_linear_fwd_act: (dy W) * gelu'(h) in one kernel
+    h = torch.randn(m, cin).to(dev)
+    got = ops._linear_act(g.to(dev), ops._linear_pack(wg.detach(), 1), None, cout, cin, 2, aux_in=h)
+    ref = torch.ops.aten.gelu_backward((g.double() @ w.double()), h.cpu().double())
+    assert float((got.cpu().double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("c,heads,drop_path", [(48, 8, 0.0), (192, 8, 0.2)])
+def test_single_node_encoder_layer_matches_composed_modules(monkeypatch, c, heads, drop_path):
+    """Same kernels, same RNG consumption: forward identical, gradients equal up to the rounding of where the GELU
+    derivative and the residual sums are applied."""
+    from openseg3d_amd import scene, swformer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    part = swformer.SparseWindowPartitionLayer({0: {"max_tokens": 800, "batching_range": [0, 100000]}}, [10, 10, 8],
+                                               [360.0, 360.0, 16.0])
+    pts = scene.make_small_scene(5, 9000, extent=12.0)
+    coords = np.unique(np.floor((pts[:, :3] - pts[:, :3].min(0)) / 0.4).astype(np.int32)[:, ::-1], axis=0)
+    coords = torch.from_numpy(np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords], 1)).to(dev)
+    plan = part.plan(coords, 1, c)
+    layer = swformer.EncoderLayer(c, heads, 2 * c, drop_path_rate=drop_path).to(dev).train()
+    with torch.no_grad():
+        layer.win_attn.self_attn.tau.fill_(0.3)
+    x0 = torch.randn(coords.shape[0], c, device=dev)
+    gout = torch.randn_like(x0)
+    results = []
+    for fused in (True, False):
+        monkeypatch.setattr(swformer, "FUSED_LAYER", fused)
+        layer.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        x = x0.clone().requires_grad_(True)
+        y = layer(x * 1.0, plan.pos[0], plan.index[0])
+        assert ("EncoderLayerFn" in type(y.grad_fn).__name__) == fused
+        y.backward(gout)
+        results.append((y.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+    (ya, dxa, ga), (yb, dxb, gb) = results
+    assert torch.equal(ya, yb)
+    assert float((dxa - dxb).abs().max()) <= 1e-5 * max(1.0, float(dxb.abs().max()))
+    for k in gb:
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * max(1.0, float(gb[k].abs().max())), k

@@ -11,6 +11,7 @@ ds = config.DatasetSpec(cfg)
 model = segformer.build_segmentor(cfg, ds).to(dev).eval()
 orig = ops.window_partition
 seen = []
+shares = []
 
 
 def spy(*a, **k):
@@ -19,6 +20,8 @@ def spy(*a, **k):
     n = n[n > 0]
     seen.append((int(w.tok.shape[0]), int(n.shape[0]), int(n.max()), float(n.mean()), float((n * n).sum()), int((n > 512).sum()),
                  int((n > 1024).sum())))
+    n2 = float((n * n).sum())
+    shares.append([float((n[(n > lo) & (n <= hi)] ** 2).sum()) / n2 for lo, hi in ((0, 32), (32, 64), (64, 128), (128, 256), (256, 100000))])
     return w
 
 
@@ -28,3 +31,5 @@ with torch.no_grad():
     model(b)
 for s in seen:
     print("tokens %6d windows %5d max %5d mean %6.1f sum_n2 %.3g  >512: %d  >1024: %d" % s)
+for sh in shares:
+    print("share of sum n^2 by window size (<=32, <=64, <=128, <=256, >256):", " ".join("%.2f" % v for v in sh))
