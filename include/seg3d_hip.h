@@ -187,13 +187,6 @@ int seg3d_linear_pack_weight(const float* weight, int32_t cin, int32_t cout, int
 int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
                      const float* addend /* [m, cout] added in the epilogue, or NULL */, int32_t cin, int32_t cout,
                      float* y, void* stream);
-/* The GELU of the encoder MLP (fc1 -> GELU -> fc2, point_transformer_layer.py:260-276; exact erf form, as nn.GELU())
- * folded into the GEMM on either side of it:
- *   mode 1  y = gelu(x . W^T + bias); aux_out (or NULL) receives the pre-activation, which the backward needs
- *   mode 2  y = (x . W^T) * gelu'(aux_in)   -- with x = dy and W packed transposed this is fc2's input gradient already
- *           multiplied by the GELU derivative at the saved pre-activation aux_in [m, cout] */
-int seg3d_linear_fwd_act(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/, int32_t cin,
-                         int32_t cout, int32_t mode, const float* aux_in, float* aux_out, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /

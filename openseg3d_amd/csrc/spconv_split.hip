@@ -111,31 +111,13 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
     if (t < items) pack_item(jb.src, jb.cin_src, jb.cout_src, jb.kk, jb.transpose, jb.flip, t, jb.dst);
 }
 
-// Optional epilogue of the dense (Linear) instantiation -- the GELU of the encoder MLP (point_transformer_layer.py:260-276)
-// rides in the GEMMs on either side of it instead of being two elementwise passes over [rows, 2C]:
-//   kEpiGelu     : aux_out (may be null) = x W^T + b (kept for the backward), y = gelu(x W^T + b)      (exact erf form)
-//   kEpiGeluGrad : y = (dy W) * gelu'(aux_in)                                                       (input gradient of fc2)
-enum { kEpiNone = 0, kEpiGelu = 1, kEpiGeluGrad = 2 };
-struct Epilogue {
-    int mode;
-    const float* aux_in;
-    float* aux_out;
-};
-
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float v) {
-    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-    const float pdf = expf(-0.5f * v * v) * 0.39894228040143267794f;
-    return cdf + v * pdf;
-}
-
 template <int NBT, int RB, bool DENSE>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ addend,
                                                               const int32_t* __restrict__ row_order, int cin, int cout,
-                                                              float* __restrict__ y, Epilogue epi) {
+                                                              float* __restrict__ y) {
     constexpr int kW = 4;
     constexpr int kSlot = NBT * 128;  // uint4 per staged chunk (NBT x {hi, lo} x 64 lanes)
     constexpr int kPieces = NBT * 2;  // 1-KiB wave-instructions per chunk
@@ -321,18 +303,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             if (opos < m_out) {
                 const int64_t orow = row_order ? (int64_t)row_order[opos] : opos;
                 float* yr = y + orow * cout + nb0 * 16 + c16;
-                if (DENSE && epi.mode == kEpiGelu) {
-#pragma unroll
-                    for (int n = 0; n < NBT; ++n) {
-                        const float v = acc[rb][n][r];
-                        if (epi.aux_out) epi.aux_out[orow * cout + nb0 * 16 + c16 + n * 16] = v;
-                        yr[n * 16] = gelu_f(v);
-                    }
-                } else if (DENSE && epi.mode == kEpiGeluGrad) {
-                    const float* hr = epi.aux_in + orow * cout + nb0 * 16 + c16;
-#pragma unroll
-                    for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r] * gelu_grad_f(hr[n * 16]);
-                } else if (addend) {  // y = x W^T + b + addend: a second gradient path summed in the epilogue
+                if (addend) {  // y = x W^T + b + addend: a second gradient path summed in the epilogue
                     const float* ar = addend + orow * cout + nb0 * 16 + c16;
 #pragma unroll
                     for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r] + ar[n * 16];
@@ -346,14 +317,14 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 
 template <int NBT, int RB>
 int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const float* addend,
-                 const int32_t* row_order, int cin, int cout, float* y, Epilogue epi, hipStream_t st) {
+                 const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
     if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, epi);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y);
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, epi);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -375,9 +346,8 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
     return SEG3D_OK;
 }
 
-static int split_fwd_epi(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                         const float* addend, const int32_t* row_order, int cin, int cout, float* y, Epilogue epi,
-                         hipStream_t st) {
+int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
     // (19k, 7k) and wide channels and run better on twice as many 96-column workgroups (measured per layer,
     // profiles/README.md); narrower tiles re-gather the rows too often.
@@ -394,18 +364,13 @@ static int split_fwd_epi(const float* x, const int32_t* nbr, int64_t m_out, cons
         if (w > 0 && nb % w == 0) pick = w;
     }
     switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, epi, st);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, epi, st);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, epi, st);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, epi, st);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, epi, st);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, epi, st);
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
     }
-}
-
-int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
-    return split_fwd_epi(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, Epilogue{kEpiNone, nullptr, nullptr}, st);
 }
 
 // ------------------------------------------------------------------ dense Linear layers through the same kernel
@@ -441,16 +406,6 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
     return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, as_stream(stream));
-}
-
-int seg3d_linear_fwd_act(const float* x, int64_t m, const void* w_packed, const float* bias, int32_t cin, int32_t cout,
-                         int32_t mode, const float* aux_in, float* aux_out, float* y, void* stream) {
-    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
-    if (mode != kEpiGelu && mode != kEpiGeluGrad) return SEG3D_EINVAL;
-    if (m == 0) return SEG3D_OK;
-    if (!x || !y || (mode == kEpiGeluGrad && !aux_in)) return SEG3D_EINVAL;
-    return split_fwd_epi(x, nullptr, m, w_packed, bias, nullptr, nullptr, cin, cout, y, Epilogue{mode, aux_in, aux_out},
-                         as_stream(stream));
 }
 
 }  // extern "C"

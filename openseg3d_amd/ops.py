@@ -785,15 +785,6 @@ def window_attention(q, k, v, tau, tau_min, heads, wi):
     return _WindowAttnFn.apply(q, k, v, tau, tau_min, heads, wi)
 
 
-def _linear_act(x, packed, bias, cin, cout, mode, aux_in=None, want_pre=False):
-    """seg3d_linear_fwd_act: mode 1 -> (gelu(x W^T + b), pre-activation or None); mode 2 -> (x W^T) * gelu'(aux_in)."""
-    y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
-    pre = torch.empty_like(y) if (mode == 1 and want_pre) else None
-    _lib.call("seg3d_linear_fwd_act", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), cin, cout, int(mode), _ptr(aux_in),
-              _ptr(pre), _ptr(y), _stream())
-    return (y, pre) if mode == 1 else y
-
-
 def _linear_wgrad(x, dy, cin, cout, want_db=True):
     """(dW [cout, cin], db [cout] or None) of y = x W^T + b from the tall-skinny split-bf16 kernel (deterministic)."""
     dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
@@ -802,40 +793,6 @@ def _linear_wgrad(x, dy, cin, cout, want_db=True):
     ws = _workspace(ws_bytes, dy.device)
     _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream())
     return dw, db
-
-
-class _LinearGeluFn(torch.autograd.Function):
-    """gelu(x W^T + b) with the activation in the GEMM epilogue (forward) and its derivative applied to the incoming
-    gradient in one elementwise pass (backward); used on paths that do not go through _EncoderLayerFn."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        x = _f32c(x)
-        cout, cin = weight.shape
-        keep = any(ctx.needs_input_grad)  # forward runs with grad mode off: ask the node, not torch.is_grad_enabled()
-        y, pre = _linear_act(x, _linear_pack(weight, 0), None if bias is None else _f32c(bias), cin, cout, 1, want_pre=keep)
-        ctx.save_for_backward(x, weight, pre)
-        ctx.has_bias = bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight, pre = ctx.saved_tensors
-        cout, cin = weight.shape
-        dh = torch.ops.aten.gelu_backward(_f32c(dy), pre)
-        dx = _linear_apply(dh, _linear_pack(weight, 1), None, cout, cin) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if ctx.needs_input_grad[1]:
-            dw, db = _linear_wgrad(x, dh, cin, cout, ctx.has_bias)
-        return dx, dw, db
-
-
-def linear_gelu(x, weight, bias):
-    """F.gelu(F.linear(x, weight, bias)) (exact erf form) in one kernel when the shape fits the MFMA tiles."""
-    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 16 == 0 and weight.shape[1] % 8 == 0
-            and CONV_PRECISION == "bf16x3" and (weight.shape[1] % 16 == 0 or not torch.is_grad_enabled())):
-        return _LinearGeluFn.apply(x, weight, bias)
-    return torch.nn.functional.gelu(linear(x, weight, bias))
 
 
 class _Ctx:
@@ -854,8 +811,10 @@ class _EncoderLayerFn(torch.autograd.Function):
         a  = out_proj(window_attention(in_proj(x, pos)))          x1 = x  + s1 * LN1(a)
         m  = fc2(gelu(fc1(x1)))                                   x2 = x1 + s2 * LN2(m)
     Same kernels as the composed modules.  What the single node buys: the two residual-path gradients are added in the
-    epilogue of the branch's last input-gradient GEMM (no autograd accumulation adds), the GELU lives in the fc1 / fc2
-    GEMM epilogues both ways (no elementwise passes over [rows, 2C]), and the engine walks 1 node instead of 9."""
+    epilogue of the branch's last input-gradient GEMM (no autograd accumulation adds) and the engine walks 1 node
+    instead of 9.  (The GELU stays a separate elementwise pass: folded into the fc1 / fc2 GEMM epilogues its erf ran
+    serialised after the MFMA loop -- 96 evaluations per lane -- and cost 1.6 ms per step more than the two passes it
+    saved, which hide the erf behind their memory traffic.)"""
 
     @staticmethod
     def forward(ctx, x, pos, w_in, b_in, tau, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, meta):
@@ -870,7 +829,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         c_n1 = _Ctx(True, True, True, True, False, False)
         x1 = _LayerNormResidualFn.forward(c_n1, a, x, g1, be1, eps1, s1)
         hid = w1.shape[0]
-        g, h = _linear_act(x1, _linear_pack(w1, 0), b1, c, hid, 1, want_pre=True)
+        h = _linear_apply(x1, _linear_pack(w1, 0), b1, c, hid)
+        g = torch.nn.functional.gelu(h)
         m = _linear_apply(g, _linear_pack(w2, 0), b2, hid, c)
         c_n2 = _Ctx(True, True, True, True, False, False)
         x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
@@ -884,9 +844,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         o, x1, h, g, w_out, w1, w2 = ctx.saved_tensors
         dx2 = _f32c(dx2)
         c, hid = x1.shape[1], w1.shape[0]
-        # MLP branch: LN2 -> fc2 (x gelu') -> fc1, the residual gradient dx2 joins in fc1's epilogue
+        # MLP branch: LN2 -> fc2 -> gelu' -> fc1, the residual gradient dx2 joins in fc1's epilogue
         dm, _, dg2, dbe2, _, _ = _LayerNormResidualFn.backward(c_n2, dx2)
-        dh = _linear_act(dm, _linear_pack(w2, 1), None, c, hid, 2, aux_in=h)
+        dh = torch.ops.aten.gelu_backward(_linear_apply(dm, _linear_pack(w2, 1), None, c, hid), h)
         dw2, db2 = _linear_wgrad(g, dm, hid, c)
         d_x1 = _linear_apply(dh, _linear_pack(w1, 1), None, hid, c, addend=dx2)
         dw1, db1 = _linear_wgrad(x1, dh, c, hid)
