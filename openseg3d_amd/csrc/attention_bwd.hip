@@ -364,14 +364,26 @@ __global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __r
 }
 
 // dtau = sum of the per-wave partials in a fixed order
-__global__ __launch_bounds__(256) void tau_reduce(const float* __restrict__ part, int count, float* __restrict__ dtau) {
-    float v = 0.f;
-    for (int i = threadIdx.x; i < count; i += 256) v += part[i];
+__global__ __launch_bounds__(1024) void tau_reduce(const float* __restrict__ part, int count, float* __restrict__ dtau) {
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;  // independent chains: loads overlap
+    int i = threadIdx.x;
+    for (; i + 3072 < count; i += 4096) {
+        v0 += part[i];
+        v1 += part[i + 1024];
+        v2 += part[i + 2048];
+        v3 += part[i + 3072];
+    }
+    for (; i < count; i += 1024) v0 += part[i];
+    float v = (v0 + v1) + (v2 + v3);
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, SEG3D_WAVE);
-    __shared__ float w[4];
+    __shared__ float w[16];
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) dtau[0] = (w[0] + w[1]) + (w[2] + w[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += w[k];
+        dtau[0] = t;
+    }
 }
 
 // ------------------------------------------------------------------ pass B: dk, dv
@@ -529,7 +541,7 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, tile_item,
                        n_tiles, heads, mpad, tau, tau_min, dq, lddq);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(256), 0, st, ws.tau_part, (int)(grid.x * 4 * grid.y), dtau);
+    hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(1024), 0, st, ws.tau_part, (int)(grid.x * 4 * grid.y), dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_kv<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0, tile_item,
                        n_tiles, heads, mpad, dk, lddk, dv, lddv);

@@ -183,8 +183,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce(const float* __restrict__ 
     const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + col;
     float s = 0.f;
-    if (i < 2 * c)
-        for (int b = q; b < nblocks; b += 32) s += part[(int64_t)b * 2 * c + i];
+    if (i < 2 * c) {  // four independent chains (see col_partial_sum)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = q;
+        for (; b + 96 < nblocks; b += 128) {
+            s0 += part[(int64_t)b * 2 * c + i];
+            s1 += part[(int64_t)(b + 32) * 2 * c + i];
+            s2 += part[(int64_t)(b + 64) * 2 * c + i];
+            s3 += part[(int64_t)(b + 96) * 2 * c + i];
+        }
+        for (; b < nblocks; b += 32) s0 += part[(int64_t)b * 2 * c + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[q][col] = s;
     __syncthreads();
     if (q == 0 && i < 2 * c) {
@@ -251,8 +261,18 @@ __global__ __launch_bounds__(kThreads) void col_reduce_kernel(const float* __res
 __device__ __forceinline__ float col_partial_sum(const float* __restrict__ part, int nblocks, int c2, int i, float (*red)[33]) {
     const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
     float s = 0.f;
-    if (i < c2)
-        for (int b = q; b < nblocks; b += 32) s += part[(int64_t)b * c2 + i];
+    if (i < c2) {  // four independent chains: the loads overlap instead of queueing behind one accumulator
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = q;
+        for (; b + 96 < nblocks; b += 128) {
+            s0 += part[(int64_t)b * c2 + i];
+            s1 += part[(int64_t)(b + 32) * c2 + i];
+            s2 += part[(int64_t)(b + 64) * c2 + i];
+            s3 += part[(int64_t)(b + 96) * c2 + i];
+        }
+        for (; b < nblocks; b += 32) s0 += part[(int64_t)b * c2 + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[q][col] = s;
     __syncthreads();
     float t = red[0][col];

@@ -189,25 +189,48 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
     }
 }
 
-// dw[i] / db[i - nw] = sum over chunks of part[c][i] in a fixed order: a workgroup owns 32 columns, its 8 row
-// lanes take chunks q, q+8, .. and are combined through LDS in lane order
+// dw[i] / db[i - nw] = sum over chunks of part[c][i] in a fixed order: a workgroup owns 64 column quads (16-B loads, 1 KiB
+// per wave instruction), its 4 chunk lanes take chunks q, q+4, .. with four independent accumulators (loads in flight
+// instead of a serial chain) and are combined through LDS in lane order.  n and nw are multiples of 4.
 __global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restrict__ part, int chunks, int64_t n,
                                                           int64_t nw, float* __restrict__ dw,
                                                           float* __restrict__ db) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + col;
-    float s = 0.f;
-    if (i < n)
-        for (int c = q; c < chunks; c += 8) s += part[(int64_t)c * n + i];
-    red[q][col] = s;
+    __shared__ float4 red[4][64];
+    const int cq = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + cq) * 4;
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        int c = q;
+        for (; c + 12 < chunks; c += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)(c + 4 * u) * n + i);
+                acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+            }
+        }
+        for (; c < chunks; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)c * n + i);
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        }
+    }
+    float4 s;
+    s.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+    s.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    s.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+    s.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+    red[q][cq] = s;
     __syncthreads();
     if (q == 0 && i < n) {
-        float t = red[0][col];
+        float4 t = red[0][cq];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][col];
-        if (i < nw) dw[i] = t;
-        else if (db) db[i - nw] = t;
+        for (int k = 1; k < 4; ++k) {
+            const float4 v = red[k][cq];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        if (i < nw) *reinterpret_cast<float4*>(dw + i) = t;
+        else if (db) *reinterpret_cast<float4*>(db + (i - nw)) = t;
     }
 }
 
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restric
 
 // part[chunks][n] -> dw[0, nw) and db[0, n - nw) (db nullable); also used by the sparse wgrad (wgrad_split.hip)
 int wgrad_chunk_reduce(const float* part, int chunks, int64_t n, int64_t nw, float* dw, float* db, hipStream_t st) {
-    hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(n, 32)), dim3(256), 0, st, part, chunks, n, nw, dw, db);
+    hipLaunchKernelGGL(wgrad_dense_reduce, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, part, chunks, n, nw, dw, db);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
