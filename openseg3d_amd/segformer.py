@@ -226,8 +226,7 @@ class NarrowBatchNorm1d(nn.BatchNorm1d):
     def forward(self, x):
         if not self.training or not self.track_running_stats:
             return super().forward(x)
-        mean = x.mean(dim=0)
-        var = x.var(dim=0, unbiased=False)
+        var, mean = torch.var_mean(x, dim=0, unbiased=False)  # one Welford pass instead of two column reductions
         with torch.no_grad():
             n = x.shape[0]
             self.num_batches_tracked += 1
