@@ -191,26 +191,27 @@ class EncoderLayer(nn.Module):
         self.mlp = MLP(d_model, mlp_hidden_dim, drop=drop)
         self.drop_path_rate = float(drop_path_rate)
 
-    def forward(self, x, pos, wi):
+    def forward(self, x, pos, wi, scales=None):
+        """``scales``: optional (s1, s2) per-row DropPath factors made by the enclosing block for all its layers at once;
+        None = draw them here (seg3d/models/layers/drop.py:6-19)."""
         at, mlp = self.win_attn.self_attn, self.mlp
+        drop = self.training and self.drop_path_rate > 0.0
+        s1 = s2 = None
+        if drop:
+            s1, s2 = scales if scales is not None else (drop_path_scale(x, self.drop_path_rate),
+                                                        drop_path_scale(x, self.drop_path_rate))
         if (FUSED_LAYER and torch.is_grad_enabled() and x.requires_grad and not mlp.drop and at.in_proj_bias is not None
                 and ops.encoder_layer_fits(x, at.embed_dim, mlp.fc1.out_features, at.num_heads)):
             # training: the whole layer is one autograd node (ops._EncoderLayerFn)
-            drop = self.training and self.drop_path_rate > 0.0
-            s1 = drop_path_scale(x, self.drop_path_rate) if drop else None
-            s2 = drop_path_scale(x, self.drop_path_rate) if drop else None
             meta = (at.num_heads, at.tau_min, wi, self.norm1.eps, self.norm2.eps, s1, s2)
             return ops._EncoderLayerFn.apply(x, pos, at.in_proj_weight, at.in_proj_bias, at.tau, at.out_proj.weight,
                                              at.out_proj.bias, self.norm1.weight, self.norm1.bias, mlp.fc1.weight,
                                              mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, self.norm2.weight,
                                              self.norm2.bias, meta)
         a = self.win_attn(x, pos, wi)
-        if self.drop_path_rate == 0.0 or not self.training:  # fused residual + LayerNorm
-            x = ops.layer_norm_residual(a, x, self.norm1)
-            return ops.layer_norm_residual(self.mlp(x), x, self.norm2)
-        # stochastic depth rides in the same pass: x + mask/keep * LN(.)
-        x = ops.layer_norm_residual(a, x, self.norm1, rowscale=drop_path_scale(x, self.drop_path_rate))
-        return ops.layer_norm_residual(self.mlp(x), x, self.norm2, rowscale=drop_path_scale(x, self.drop_path_rate))
+        # fused residual + LayerNorm; stochastic depth rides in the same pass: x + mask/keep * LN(.)
+        x = ops.layer_norm_residual(a, x, self.norm1, rowscale=s1)
+        return ops.layer_norm_residual(self.mlp(x), x, self.norm2, rowscale=s2)
 
 
 class SWFormerBlock(nn.Module):
@@ -221,11 +222,24 @@ class SWFormerBlock(nn.Module):
         self.layers = nn.ModuleList(
             EncoderLayer(d_model, nhead, int(d_model * mlp_ratio), drop=drop, attn_drop=attn_drop,
                          drop_path_rate=rates[i]) for i in range(depth))
+        self._keep = None  # [2 * depth, 1] keep probabilities on the device (built on first use)
 
     def forward(self, voxel_info):
         x, plan = voxel_info["voxel_features"], voxel_info["plan"]
         half = int(self.depth / 2)  # first depth//2 layers on the unshifted windows (:321-337)
+        scales = self.drop_path_scales(x) if self.training else None
         for i, layer in enumerate(self.layers):
             s = 0 if i < half else 1
-            x = layer(x, plan.pos[s], plan.index[s])
+            x = layer(x, plan.pos[s], plan.index[s], None if scales is None else (scales[2 * i], scales[2 * i + 1]))
         return x
+
+    def drop_path_scales(self, x):
+        """[2 * depth, rows] DropPath factors mask / keep_prob of all layers of the block from ONE uniform draw (4 launches
+        per block instead of 4 per layer); same distribution as drop.py:6-19, rows of rate-0 layers are never read."""
+        rates = [layer.drop_path_rate for layer in self.layers]
+        if not any(r > 0.0 for r in rates):
+            return None
+        if self._keep is None or self._keep.device != x.device:
+            self._keep = torch.tensor([1.0 - r for r in rates for _ in (0, 1)], dtype=torch.float32, device=x.device)[:, None]
+        u = torch.rand((2 * self.depth, x.shape[0]), dtype=torch.float32, device=x.device)
+        return (u < self._keep).to(torch.float32).div_(self._keep)
