@@ -279,12 +279,14 @@ class DeepFusionBlock(nn.Module):
         xyz = points.contiguous() if self.faithful_stride else points[:, :3].contiguous()
         knn_ids, _ = ops.knn_query(self.n_neighbors, xyz, xyz, point_id_offset, point_id_offset)
         knn_ids = knn_ids.long()
-        attn = torch.einsum("nc,nkc->nk", q, k[knn_ids]) / (q.shape[-1] ** 0.5)
+        # per-point dot products with 16 gathered rows: broadcast multiply + reduce (HBM-bound, ~0.3 ms on 233 k points);
+        # the einsum form goes to rocBLAS batched GEMM with 1 x 32 x 16 problems (3.7 ms per call, 22 ms per step)
+        attn = (q.unsqueeze(1) * k[knn_ids]).sum(dim=-1) / (q.shape[-1] ** 0.5)
         invalid = (image_features.sum(dim=1) == 0)[knn_ids]
         attn = attn.masked_fill(invalid, float("-inf"))
         attn = torch.nan_to_num(torch.softmax(attn, dim=-1))
         attn = self.attn_dropout(attn)
-        return self.c_proj(torch.einsum("nk,nkc->nc", attn, v[knn_ids]))
+        return self.c_proj((attn.unsqueeze(-1) * v[knn_ids]).sum(dim=1))
 
 
 class Segformer(nn.Module):
