@@ -357,6 +357,12 @@ int seg3d_knn_level_build(const float* xyz, int64_t n, const int32_t* offset, in
                           int64_t capacity, void* workspace, size_t workspace_bytes, void* stream);
 int seg3d_knn_query_order(const float* new_xyz, int64_t m, const int32_t* new_offset, int32_t batch_size, float cell,
                           int32_t* order, void* workspace, size_t workspace_bytes, void* stream);
+/* a10/a11 scheduling aid: order [m] = rows of coords [m,4] (b,z,y,x) grouped by the parity of (z, y, x), original order
+ * kept inside a group (stable 3-bit device radix sort).  Under SparseConv3d(k=3, s=2, p=1) the kernel offsets that can
+ * reach a fine site are fixed by its parity, so 128-row tiles of same-parity rows of the inverse table visit 1-8 of
+ * the 27 offsets (row_order of seg3d_spconv_fwd).  Workspace: seg3d_knn_level_workspace_bytes(m). */
+int seg3d_parity_order(const int32_t* coords, int64_t m, int32_t* order, void* workspace, size_t workspace_bytes,
+                       void* stream);
 typedef struct {
   const float* sorted_xyz;     /* [n,3] points in this level's cell order */
   const int32_t* src_index;    /* [n] original row of each sorted point */

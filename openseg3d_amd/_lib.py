@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "seg3d_lovasz_softmax_bwd": (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
     "seg3d_knn_level_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "seg3d_knn_level_build": (ctypes.c_int, [_p, _i64, _p, _i32, _f, _p, _p, _p, _p, _p, _i64, _p, ctypes.c_size_t, _p]),
+    "seg3d_parity_order": (ctypes.c_int, [_p, _i64, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_knn_query_order": (ctypes.c_int, [_p, _i64, _p, _i32, _f, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_knn_grid_query": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_knn_query": (ctypes.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),

@@ -163,6 +163,16 @@ __global__ __launch_bounds__(kThreads) void knn_level_finish(const unsigned long
     }
 }
 
+// key of a site for the parity order of the strided / inverse conv tables: (z & 1, y & 1, x & 1)
+__global__ __launch_bounds__(kThreads) void parity_keys(const int32_t* __restrict__ coords, int m,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ rows) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= m) return;
+    const int32_t* c = coords + 4 * (int64_t)i;
+    keys[i] = (unsigned long long)(((c[1] & 1) << 2) | ((c[2] & 1) << 1) | (c[3] & 1));
+    rows[i] = (uint32_t)i;
+}
+
 __global__ __launch_bounds__(kThreads) void knn_copy_order(const uint32_t* __restrict__ srows, int m, int32_t* __restrict__ order) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i < m) order[i] = (int32_t)srows[i];
@@ -440,6 +450,28 @@ extern "C" int seg3d_knn_query_order(const float* new_xyz, int64_t m, const int3
     const int rc = sorted_cells(new_xyz, m, new_offset, batch_size, cell, sb, st, &skeys, &srows);
     if (rc != SEG3D_OK) return rc;
     hipLaunchKernelGGL(knn_copy_order, dim3((unsigned)ceil_div64(m, kThreads)), dim3(kThreads), 0, st, srows, (int)m, order);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+// Rows of a site list grouped by the parity of (z, y, x), original order kept inside a group (a stable 3-bit radix
+// sort): the processing order of the strided / inverse conv tables (spconv.SiteLevel.parity_order).  Workspace as
+// seg3d_knn_level_workspace_bytes(m).
+extern "C" int seg3d_parity_order(const int32_t* coords, int64_t m, int32_t* order, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (m < 0 || m >= (int64_t)0x7FFFFFF0) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!coords || !order) return SEG3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    SortBuffers sb;
+    if (!carve_sort(workspace, workspace_bytes, m, &sb)) return SEG3D_EWORKSPACE;
+    hipLaunchKernelGGL(parity_keys, dim3((unsigned)ceil_div64(m, kThreads)), dim3(kThreads), 0, st, coords, (int)m, sb.k0, sb.v0);
+    SEG3D_CHECK_LAUNCH();
+    rocprim::double_buffer<SortKey> kb(sb.k0, sb.k1);
+    rocprim::double_buffer<uint32_t> vb(sb.v0, sb.v1);
+    size_t bytes = sb.tmp_bytes;
+    if (rocprim::radix_sort_pairs(sb.tmp, bytes, kb, vb, (size_t)m, 0u, 3u, st) != hipSuccess) return SEG3D_ELAUNCH;
+    hipLaunchKernelGGL(knn_copy_order, dim3((unsigned)ceil_div64(m, kThreads)), dim3(kThreads), 0, st, vb.current(), (int)m, order);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

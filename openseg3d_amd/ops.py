@@ -158,6 +158,18 @@ def downsample_coords(coords, batch_size, spatial_shape):
     return out[: int(count.item())], shape_out
 
 
+def parity_order(coords):
+    """int32 [M] permutation: rows of coords [M, 4] grouped by the parity of (z, y, x), stable inside a group."""
+    _need_gpu(coords)
+    coords = _i32c(coords)
+    m = coords.shape[0]
+    order = torch.empty((m,), dtype=torch.int32, device=coords.device)
+    ws_bytes = _lib.query("seg3d_knn_level_workspace_bytes", m)
+    ws = _workspace(ws_bytes, coords.device)
+    _lib.call("seg3d_parity_order", _ptr(coords), m, _ptr(order), _ptr(ws), ws_bytes, _stream())
+    return order
+
+
 def rulebook_strided(h_in, coords_out):
     m_in, m_out = h_in.coords.shape[0], coords_out.shape[0]
     dev = coords_out.device

@@ -73,9 +73,7 @@ class SiteLevel:
         k=3, s=2, p=1 conv the kernel offsets that can reach a fine site are fixed by its parity (1, 2, 4 or 8 of
         the 27), so tiles of same-parity rows of the inverse table skip the other offsets wholesale."""
         if self._parity is None:
-            c = self.coords
-            key = (c[:, 1] & 1) * 4 + (c[:, 2] & 1) * 2 + (c[:, 3] & 1)
-            self._parity = torch.sort(key, stable=True)[1].to(torch.int32)
+            self._parity = ops.parity_order(self.coords)  # stable 3-bit device radix sort (seg3d_parity_order)
         return self._parity
 
     def down(self):

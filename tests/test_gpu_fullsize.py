@@ -73,6 +73,10 @@ def test_fullsize_rulebook_properties(dev, full):
         i = torch.nonzero(nbr[k] >= 0).view(-1)
         delta = level.coords[nbr[k][i].long()] - level.coords[i]
         assert bool((delta == torch.tensor([0, dz, dy, dx], device=dev, dtype=torch.int32)).all())
+        # parity order = stable sort by (z & 1, y & 1, x & 1)
+        cz = level.coords
+        key = (cz[:, 1] & 1) * 4 + (cz[:, 2] & 1) * 2 + (cz[:, 3] & 1)
+        assert torch.equal(level.parity_order(), torch.sort(key, stable=True)[1].int())
         coarse, fwd, inv = level.down()
         # output sites of SparseConv3d(k=3, s=2, p=1): every o with 2o - 1 + k = c for some active c, sorted, unique
         c = level.coords[:, 1:].long()
