@@ -6,10 +6,11 @@ Host-side mirror of the reference's default model (``cfg.MODEL.SEGMENTOR == 'seg
 Same constructor arguments, same ``forward(batch_dict) -> OrderedDict`` contract and the same
 state_dict keys / shapes (tests/golden/segformer_keys.json), so reference checkpoints load.
 
-What runs where: voxel-feature reduce, every sparse convolution, window partition + attention and
-the voxel->point gather run in libseg3d_hip.so; per-point / per-voxel dense layers (Linear, BN, LN,
-GELU) stay on torch's GEMM / elementwise kernels.  Index structures (site levels, neighbour tables,
-window CSRs, point->voxel CSR) are built once per batch and shared by all layers that use them.
+What runs where: voxel-feature reduce, every sparse convolution, window partition + attention, every Linear /
+LayerNorm / BatchNorm(+ReLU) pass with MFMA-sized channels, the voxel->point gather, kNN and the training criterion run
+in libseg3d_hip.so; torch supplies GELU, a few elementwise adds / concatenations, the 6 -> 64 and -> 22 GEMMs (rocBLAS),
+the optimizer and autograd's bookkeeping.  Index structures (site levels, neighbour tables, window CSRs, point->voxel
+CSR) are built once per batch, before the first feature kernel, and shared by all layers that use them.
 Scope: all three shipped configs -- single sweep (cartesian / cylinder) and multi-sweep with optional
 image-feature fusion (DeepFusionBlock over seg3d_knn_query).
 """

@@ -3,8 +3,8 @@
 Only the surface the reference touches is provided (call sites
 seg3d/utils/spconv_utils.py:13-32, seg3d/models/backbones/pointtransformer.py:13-113,184-189):
 ``SparseConvTensor``, ``SubMConv3d``, ``SparseConv3d``, ``SparseInverseConv3d``,
-``SparseSequential``, ``SparseModule``.  ``openseg3d_amd.compat.install()`` registers this module
-as ``spconv.pytorch`` so the reference's model files import it unchanged.
+``SparseSequential``, ``SparseModule``.  INTEGRATION.md 2.2 shows the two-line ``sys.modules`` registration that
+makes the reference's model files import this module as ``spconv.pytorch`` unchanged.
 
 Design differences from spconv (MI355X-first):
   * a resolution level (``SiteLevel``) owns its coordinate hash and its neighbour tables; tables

@@ -14,7 +14,9 @@ What changed underneath (MI355X-first):
     needs (windows per shift) are fetched once per stage;
   * activation checkpointing (point_transformer_layer.py:321-337) is not used: 288 GB of HBM holds
     the activations of a 180 k-point scene many times over.
-Dense projections / MLP / LayerNorm stay on torch (rocBLAS/hipBLASLt GEMMs).
+  * in training an encoder layer is ONE autograd node (ops._EncoderLayerFn): in-projection, attention, out-projection,
+    residual + DropPath + LayerNorm and the MLP run as a fixed sequence of library kernels, the residual-path
+    gradients join in GEMM epilogues; only GELU and ``x + pos`` are torch elementwise kernels.
 """
 import math
 import os
