@@ -133,6 +133,34 @@ def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
     assert float((ye.cpu().double() - yre).abs().max()) < 5e-5
 
 
+def test_eval_batchnorm_fold_follows_training_and_checkpoint_loads():
+    """The cached eval-mode affine (scale, shift) must track the running statistics: after training steps (buffers
+    updated by the kernel through raw pointers) and after load_state_dict."""
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    bn = nn.BatchNorm1d(32, eps=1e-3, momentum=0.1).to(dev)
+    ref = nn.BatchNorm1d(32, eps=1e-3, momentum=0.1).to(dev)
+    ref.load_state_dict(bn.state_dict())
+    x = torch.randn(500, 32, device=dev) * 2 + 1
+
+    def check():
+        bn.eval(), ref.eval()
+        with torch.no_grad():
+            assert float((ops.batch_norm_act(x, bn, relu=False) - ref(x)).abs().max()) < 1e-5
+
+    check()
+    check()  # second call comes from the cache
+    for _ in range(3):
+        bn.train(), ref.train()
+        ops.batch_norm_act(x * 1.5 - 2.0, bn, relu=True)
+        ref(x * 1.5 - 2.0)
+    check()
+    sd = {k: (v * 0.5 + 0.25 if v.is_floating_point() else v) for k, v in ref.state_dict().items()}
+    bn.load_state_dict(sd), ref.load_state_dict(sd)
+    check()
+
+
 @pytest.mark.parametrize("n,c", [(50000, 22), (1, 22), (777, 5)])
 def test_cross_entropy_matches_torch(n, c):
     from openseg3d_amd import ops
