@@ -89,6 +89,16 @@ def conv_roofline(model, batch, dev):
         records.append((nbr, cin, cout, e0, e1))
         return y
 
+    orig_act = ops.conv_act  # inference form of the conv blocks (BatchNorm folded, ReLU / residual in the epilogue)
+
+    def timed_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True):  # noqa: E306
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_act(x, nbr, packed, bias, cin, cout, order, addend, relu)
+        e1.record()
+        records.append((nbr, cin, cout, e0, e1))
+        return y
+
     attn_records = []
     orig_attn = ops.window_attention_packed
 
@@ -101,6 +111,7 @@ def conv_roofline(model, batch, dev):
         return o
 
     ops._conv_apply = timed
+    ops.conv_act = timed_act
     ops.window_attention_packed = timed_attn
     try:
         with torch.no_grad():
@@ -108,6 +119,7 @@ def conv_roofline(model, batch, dev):
         torch.cuda.synchronize()
     finally:
         ops._conv_apply = orig
+        ops.conv_act = orig_act
         ops.window_attention_packed = orig_attn
     # window attention (prepare + core kernels of one layer): algorithmic FLOPs 4*C*sum_w n_w^2
     sq_cache, a_flop, a_ms = {}, 0.0, 0.0

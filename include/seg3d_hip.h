@@ -140,6 +140,15 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
                         Results do not depend on it; strided / inverse tables run ~2x faster when rows are grouped by
                         coordinate parity (same active offsets per tile).  Ignored by the exact-fp32 path. */,
                      void* stream);
+/* Inference form of a conv block -- conv -> BatchNorm1d(eval) -> (+ residual) -> ReLU (ConvModule spconv_utils.py:13-32,
+ * SparseBasicBlock pointtransformer.py:47-66 / spconv_unet.py:46-66): the caller folds the BatchNorm affine into the
+ * weights before packing (W' = W * gamma * rstd per output channel) and into the bias (beta - mean * gamma * rstd
+ * (+ conv bias * gamma * rstd)); the block is then ONE launch, y = act(conv_W'(x) + bias (+ addend [m_out, cout])).
+ * Split-bf16 packs (flags bit2) only. */
+int seg3d_spconv_fwd_act(const float* x, const int32_t* nbr, int64_t m_out, int64_t m_in, const void* w_packed,
+                         int32_t pack_flags, const float* bias /*or NULL*/, const float* addend /*or NULL*/,
+                         int32_t relu, int32_t cin, int32_t cout, float* y, const int32_t* row_order /*or NULL*/,
+                         void* stream);
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout);
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out,
                        int64_t m_in, int32_t cin, int32_t cout, int32_t flags /* bit2: split-bf16 */,

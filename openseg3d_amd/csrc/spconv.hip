@@ -17,7 +17,7 @@ size_t spconv_split_packed_bytes(int cin_op, int cout_op, int kk);
 int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transpose, int flip, void* w_packed,
                       hipStream_t st);
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, hipStream_t st);
+                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st);
 size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
                        void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -316,8 +316,21 @@ int seg3d_spconv_fwd(const float* x, const int32_t* nbr, int64_t m_out, int64_t 
     if (m_out == 0) return SEG3D_OK;
     if (!x || !nbr || !y) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (pack_flags & 4) return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, nullptr, row_order, cin, cout, y, st);
+    if (pack_flags & 4) return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, nullptr, row_order, cin, cout, y, 0, st);
     return dispatch_fwd_f32(x, nbr, m_out, static_cast<const float*>(w_packed_v), bias, cin, cout, y, st);
+}
+
+/* Inference form of a conv block (conv -> BatchNorm(eval) -> (+ residual) -> ReLU, spconv_utils.py:13-32,
+ * pointtransformer.py:47-66): with the BatchNorm affine folded into the packed weights and the bias by the caller, the
+ * block is one launch -- y = act(conv(x) + bias (+ addend)).  Split-bf16 packs only. */
+int seg3d_spconv_fwd_act(const float* x, const int32_t* nbr, int64_t m_out, int64_t m_in, const void* w_packed_v,
+                         int32_t pack_flags, const float* bias, const float* addend, int32_t relu, int32_t cin,
+                         int32_t cout, float* y, const int32_t* row_order, void* stream) {
+    if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !w_packed_v || !(pack_flags & 4))
+        return SEG3D_EINVAL;
+    if (m_out == 0) return SEG3D_OK;
+    if (!x || !nbr || !y) return SEG3D_EINVAL;
+    return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, addend, row_order, cin, cout, y, relu ? 1 : 0, as_stream(stream));
 }
 
 /* a6  exact-fp32 Linear (per-point MLPs): y[m, cout] = x[m, cin] . W^T + bias on v_mfma_f32_16x16x4_f32 -- the

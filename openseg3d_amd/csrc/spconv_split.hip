@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ addend,
                                                               const int32_t* __restrict__ row_order, int cin, int cout,
-                                                              float* __restrict__ y) {
+                                                              float* __restrict__ y, int relu) {
     constexpr int kW = 4;
     constexpr int kSlot = NBT * 128;  // uint4 per staged chunk (NBT x {hi, lo} x 64 lanes)
     constexpr int kPieces = NBT * 2;  // 1-KiB wave-instructions per chunk
@@ -303,13 +303,16 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             if (opos < m_out) {
                 const int64_t orow = row_order ? (int64_t)row_order[opos] : opos;
                 float* yr = y + orow * cout + nb0 * 16 + c16;
-                if (addend) {  // y = x W^T + b + addend: a second gradient path summed in the epilogue
+                // y = act(x W^T + b (+ addend)): addend = a second gradient path, or the residual of a conv block whose
+                // BatchNorm was folded into W and b (eval); relu = that block's activation
+                const float lo = relu ? 0.0f : -INFINITY;
+                if (addend) {
                     const float* ar = addend + orow * cout + nb0 * 16 + c16;
 #pragma unroll
-                    for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r] + ar[n * 16];
+                    for (int n = 0; n < NBT; ++n) yr[n * 16] = fmaxf(acc[rb][n][r] + ar[n * 16], lo);
                 } else {
 #pragma unroll
-                    for (int n = 0; n < NBT; ++n) yr[n * 16] = acc[rb][n][r];
+                    for (int n = 0; n < NBT; ++n) yr[n * 16] = fmaxf(acc[rb][n][r], lo);
                 }
             }
         }
@@ -317,14 +320,14 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 
 template <int NBT, int RB>
 int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const float* addend,
-                 const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
+                 const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
     if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu);
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -347,7 +350,7 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
 }
 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, hipStream_t st) {
+                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
     // (19k, 7k) and wide channels and run better on twice as many 96-column workgroups (measured per layer,
     // profiles/README.md); narrower tiles re-gather the rows too often.
@@ -364,12 +367,12 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
         if (w > 0 && nb % w == 0) pick = w;
     }
     switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, st);
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
     }
 }
 
@@ -405,7 +408,7 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
     if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
-    return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, as_stream(stream));
+    return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, 0, as_stream(stream));
 }
 
 }  // extern "C"

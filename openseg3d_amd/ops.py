@@ -278,10 +278,10 @@ class PackedWeight:
         self.data, self.flags = data, flags
 
 
-def pack_weight(weight, flags):
+def pack_weight(weight, flags, use_registry=True):
     """weight [Cout,3,3,3,Cin] (or [Cout,27,Cin]) -> MFMA B-fragment stream for seg3d_spconv_fwd."""
     flags = int(flags) | _precision_flag()
-    if _registry_ok(weight) and (weight if weight._base is None else weight._base).is_leaf and weight.shape[-1] % 16 == 0:
+    if use_registry and _registry_ok(weight) and (weight if weight._base is None else weight._base).is_leaf and weight.shape[-1] % 16 == 0:
         return PackedWeight(_cached_pack(weight, 27, flags & 1, (flags >> 1) & 1), flags)
     w = _f32c(weight)
     cout, cin = w.shape[0], w.shape[-1]
@@ -296,6 +296,16 @@ def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
     _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
               cin, cout, _ptr(y), _ptr(order), _stream())
+    return y
+
+
+def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True):
+    """act(conv(x) + bias (+ addend)) in one launch (inference form of a conv block, seg3d_spconv_fwd_act)."""
+    x = _f32c(x)
+    m_out = nbr.shape[1]
+    y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
+    _lib.call("seg3d_spconv_fwd_act", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
+              _ptr(None if addend is None else _f32c(addend)), int(bool(relu)), cin, cout, _ptr(y), _ptr(order), _stream())
     return y
 
 
@@ -559,6 +569,21 @@ class _BatchNormActFn(torch.autograd.Function):
         return dx, dres, sums[1], sums[0], None, None, None, None, None
 
 
+def bn_eval_affine(bn):
+    """(scale, shift, key) with bn(x) = x * scale + shift in eval mode.  Cached on the module, keyed on the tensors'
+    versions so that loading a checkpoint invalidates it; training steps reset it (batch_norm_act) because the kernel
+    updates the running buffers through raw pointers."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_var.data_ptr(), bn.eps, getattr(bn, "_seg3d_stats_epoch", 0))
+    cached = getattr(bn, "_seg3d_eval_affine", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+        bn._seg3d_eval_affine = cached = (key, scale.contiguous(), shift.contiguous())
+    return cached[1], cached[2], key
+
+
 def batch_norm_act(x, bn, relu=True, res=None):
     """act(bn(x) (+ res)) for an nn.BatchNorm1d over [rows, C] features (C % 4 == 0), relu optional.
     Training: batch statistics (biased variance for the normalisation, unbiased into running_var, as torch);
@@ -579,7 +604,8 @@ def batch_norm_act(x, bn, relu=True, res=None):
             track = bn.training and bn.track_running_stats
             mom = 0.0
             if track:
-                bn._seg3d_eval_affine = None  # the kernel updates the running buffers through raw pointers
+                # the kernel updates the running buffers through raw pointers: tell the eval-affine cache
+                bn._seg3d_stats_epoch = getattr(bn, "_seg3d_stats_epoch", 0) + 1
                 bn.num_batches_tracked += 1
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, c)
@@ -591,14 +617,7 @@ def batch_norm_act(x, bn, relu=True, res=None):
     with torch.no_grad():
         # eval: the folded affine is a constant of the module; keyed on the tensors' versions so that loading a checkpoint
         # or resuming training invalidates it (5 tiny launches per BatchNorm per forward otherwise: ~1 ms on 27 layers)
-        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-               bn.weight.data_ptr(), bn.running_var.data_ptr(), bn.eps)
-        cached = getattr(bn, "_seg3d_eval_affine", None)
-        if cached is None or cached[0] != key:
-            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-            shift = bn.bias - bn.running_mean * scale
-            bn._seg3d_eval_affine = cached = (key, scale.contiguous(), shift.contiguous())
-        _, scale, shift = cached
+        scale, shift, _ = bn_eval_affine(bn)
         xc = _f32c(x)
         y = torch.empty_like(xc)
         r = None if res is None else _f32c(res)

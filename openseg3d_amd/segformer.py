@@ -53,6 +53,8 @@ class ConvBnAct(spconv.SparseSequential):
 
     def forward(self, x):
         conv, bn = self._modules["0"], self._modules["1"]
+        if conv.fusable_with(bn, x):  # inference: one launch, BatchNorm folded into the packed weights
+            return conv.forward_bn_act(x, bn, relu=True)
         y = conv(x)
         return y.replace_feature(ops.batch_norm_act(y.features, bn, relu=True))
 
@@ -121,6 +123,9 @@ class SparseBasicBlock(spconv.SparseModule):
         self.bn2 = norm_fn(planes)
 
     def forward(self, x):
+        if self.conv1.fusable_with(self.bn1, x) and self.conv2.fusable_with(self.bn2, x):  # inference: two launches
+            y = self.conv1.forward_bn_act(x, self.bn1, relu=True)
+            return self.conv2.forward_bn_act(y, self.bn2, relu=True, res=x.features)
         y = self.conv1(x)
         y = y.replace_feature(ops.batch_norm_act(y.features, self.bn1, relu=True))
         y = self.conv2(y)

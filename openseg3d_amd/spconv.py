@@ -19,11 +19,16 @@ Parameters: ``weight`` [Cout, 3, 3, 3, Cin] (+ ``bias`` [Cout]); default init = 
 (a=sqrt(5)) over fan_in = 27*Cin, bias uniform(+-1/sqrt(fan_in)), as torch's conv layers do.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import ops
+
+
+# Inference: conv -> BatchNorm(eval) -> (+ residual) -> ReLU as one launch (seg3d_spconv_fwd_act); 0 = separate passes.
+FUSE_EVAL_BN = os.environ.get("SEG3D_FUSE_EVAL_BN", "1") != "0"
 
 
 class SiteLevel:
@@ -122,6 +127,7 @@ class _Conv3x3x3(SparseModule):
         self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, 3, in_channels))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = None  # (weight version, packed tensor) for no-grad forwards
+        self._folded = None  # inference: (key, pack of W * bn_scale, folded bias) -- see forward_bn_act
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -147,39 +153,70 @@ class _Conv3x3x3(SparseModule):
             return ops.sparse_conv(feats, weight, self.bias, nbr, nbr_t, t_flags, None, order, order_t)
         return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight(), order, order_t)
 
+    def tables(self, x):
+        """(nbr [27, rows_out], nbr_t, pack flags of the transposed operand, row order, row order of nbr_t, output
+        SiteLevel) of this convolution on the sites of ``x``."""
+        raise NotImplementedError
+
+    def forward(self, x):
+        nbr, nbr_t, t_flags, order, order_t, level = self.tables(x)
+        return x.on_level(self._apply_tables(x.features, nbr, nbr_t, t_flags, order, order_t), level)
+
+    def fusable_with(self, bn, x):
+        """Inference only: conv -> BatchNorm(eval) -> (+ residual) -> ReLU can run as one launch."""
+        return (FUSE_EVAL_BN and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and bn.affine
+                and not self._pad_in and ops.CONV_PRECISION == "bf16x3" and x.features.is_cuda
+                and x.features.dtype == torch.float32)
+
+    def forward_bn_act(self, x, bn, relu=True, res=None):
+        """act(bn(conv(x)) (+ res)) with the BatchNorm's running-statistics affine folded into the packed weights and the
+        bias (seg3d_spconv_fwd_act); the fold is cached until the weights or the statistics change."""
+        scale, shift, bn_key = ops.bn_eval_affine(bn)
+        w = self.weight
+        key = (w._version, w.data_ptr(), None if self.bias is None else self.bias._version, bn_key)
+        if self._folded is None or self._folded[0] != key:
+            with torch.no_grad():
+                wf = (w * scale.view(-1, 1, 1, 1, 1)).contiguous()
+                bf = shift if self.bias is None else shift + self.bias * scale
+                self._folded = (key, ops.pack_weight(wf, ops.PACK_FWD, use_registry=False), bf.contiguous())
+        _, packed, bias = self._folded
+        nbr, _, _, order, _, level = self.tables(x)
+        y = ops.conv_act(x.features, nbr, packed, bias, self.in_channels, self.out_channels, order, addend=res, relu=relu)
+        return x.on_level(y, level)
+
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size=3, stride={self.stride}, " \
                f"padding={self.padding}, indice_key={self.indice_key!r}"
 
 
 class SubMConv3d(_Conv3x3x3):
-    def forward(self, x):
+    def tables(self, x):
         nbr = x.level.subm()
-        return x.replace_feature(self._apply_tables(x.features, nbr, nbr, ops.PACK_T_FLIP))
+        return nbr, nbr, ops.PACK_T_FLIP, None, None, x.level
 
 
 class SparseConv3d(_Conv3x3x3):
-    def forward(self, x):
+    def tables(self, x):
         if self.stride != 2 or self.padding != 1:
             raise NotImplementedError("only SparseConv3d(k=3, stride=2, padding=1) is on the OpenSeg3D path")
         coarse, fwd, inv = x.level.down()
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = x.level
-        return x.on_level(self._apply_tables(x.features, fwd, inv, ops.PACK_T, None, x.level.parity_order()), coarse)
+        return fwd, inv, ops.PACK_T, None, x.level.parity_order(), coarse
 
 
 class SparseInverseConv3d(_Conv3x3x3):
     def __init__(self, in_channels, out_channels, kernel_size=3, bias=True, indice_key=None):
         super().__init__(in_channels, out_channels, kernel_size, bias=bias, indice_key=indice_key)
 
-    def forward(self, x):
+    def tables(self, x):
         fine = x.indice_dict.get(self.indice_key)
         if fine is None:
             raise KeyError(f"SparseInverseConv3d: no strided conv registered indice_key={self.indice_key!r}")
         coarse, fwd, inv = fine.down()
         if coarse is not x.level:
             raise RuntimeError("SparseInverseConv3d input does not live on the paired strided conv's output sites")
-        return x.on_level(self._apply_tables(x.features, inv, fwd, ops.PACK_T, fine.parity_order(), None), fine)
+        return inv, fwd, ops.PACK_T, fine.parity_order(), None, fine
 
 
 class SparseSequential(SparseModule):

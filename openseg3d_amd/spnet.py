@@ -37,6 +37,9 @@ class SparseBasicBlock(spconv.SparseModule):
         self.sa = None  # SALayer is never enabled by the reference's SparseUnet
 
     def forward(self, x):
+        if self.se is None and self.conv1.fusable_with(self.bn1, x) and self.conv2.fusable_with(self.bn2, x):
+            y = self.conv1.forward_bn_act(x, self.bn1, relu=True)  # inference: BatchNorm folded, two launches
+            return self.conv2.forward_bn_act(y, self.bn2, relu=True, res=x.features)
         y = self.conv1(x)
         y = y.replace_feature(ops.batch_norm_act(y.features, self.bn1, relu=True))
         y = self.conv2(y)

@@ -39,3 +39,47 @@ def test_single_node_encoder_layer_matches_composed_modules(monkeypatch, c, head
     assert float((dxa - dxb).abs().max()) <= 1e-5 * max(1.0, float(dxb.abs().max()))
     for k in gb:
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * max(1.0, float(gb[k].abs().max())), k
+
+
+def test_inference_conv_blocks_fold_batchnorm_into_one_launch():
+    """conv -> BatchNorm(eval) -> (+ residual) -> ReLU through seg3d_spconv_fwd_act (no_grad) against the unfused
+    modules (grad enabled, eval): submanifold, strided and inverse convs, with a residual, after a checkpoint load."""
+    from openseg3d_amd import scene, segformer, spconv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    pts = scene.make_small_scene(6, 12000, extent=10.0)
+    coords = np.unique(np.floor((pts[:, :3] - pts[:, :3].min(0)) / 0.2).astype(np.int32)[:, ::-1], axis=0)
+    coords = torch.from_numpy(np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords], 1)).to(dev)
+    shape = [int(v) + 2 for v in coords[:, 1:].max(0)[0].tolist()]
+    norm_fn = lambda c: torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)  # noqa: E731
+    act = torch.nn.ReLU(inplace=True)
+    net = torch.nn.ModuleList([
+        segformer.conv_module(32, 48, norm_fn, act, "subm", "subm1"),
+        segformer.SparseBasicBlock(48, 48, norm_fn, act, indice_key="subm1"),
+        segformer.conv_module(48, 96, norm_fn, act, "spconv", "spconv2"),
+        segformer.SparseBasicBlock(96, 96, norm_fn, act, indice_key="subm2"),
+        segformer.conv_module(96, 48, norm_fn, act, "inverseconv", "spconv2"),
+    ]).to(dev)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m.running_mean.normal_(0, 0.3), m.running_var.uniform_(0.5, 2.0), m.weight.normal_(1, 0.2), m.bias.normal_(0, 0.2)
+    net.eval()
+    x0 = torch.randn(coords.shape[0], 32, device=dev)
+
+    def run():
+        x = spconv.SparseConvTensor(x0, coords, shape, 1)
+        for m in net:
+            x = m(x)
+        return x.features
+
+    for round_ in range(2):
+        with torch.no_grad():
+            fused = run()
+        with torch.enable_grad():
+            plain = run().detach()
+        assert float((fused - plain).abs().max()) <= 2e-4 * max(1.0, float(plain.abs().max()))
+        assert float(fused.min()) >= 0.0
+        # new statistics must invalidate the folded packs
+        sd = {k: (v * 1.3 + 0.1 if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
