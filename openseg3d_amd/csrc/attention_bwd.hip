@@ -233,8 +233,13 @@ __device__ __forceinline__ void ld2(const char* base, int64_t half_bytes, uint32
 }
 
 // ------------------------------------------------------------------ pass A: dq, dtau
+// waves per SIMD the register allocator must leave room for (the kernels are latency-bound: a wave more is worth more
+// than a few registers): pass A at dh 24 sits 5 registers above the 3-wave line without it, at dh 48 24 above the 2-wave line
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_q(BwdWs<DH> ws, const float* __restrict__ q, int ldq,
+constexpr int kBwdQWaves = DH <= 24 ? 3 : 2;
+
+template <int DH>
+__global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q(BwdWs<DH> ws, const float* __restrict__ q, int ldq,
                                                   const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                   const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
                                                   const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,

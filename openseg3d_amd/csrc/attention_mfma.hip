@@ -176,8 +176,12 @@ __global__ __launch_bounds__(256) void attn_prepare_fwd(const float* __restrict_
 // is a constant 32-bit byte offset.  No register prefetch -- measured: the extra stage registers cost more
 // occupancy than the prefetch hides.  Only the last key tile masks keys >= n.
 // Channel slices past DHS are zeroed in Q (so K needs no mask); V rows past DH only feed output rows that are never stored.
+// waves per SIMD the register allocator must leave room for: dh 24 sits one register above the 4-wave line without it
 template <int DH>
-__global__ __launch_bounds__(256) void attn_core_fwd(const __bf16* __restrict__ qp, const __bf16* __restrict__ kp,
+constexpr int kFwdWaves = DH <= 24 ? 4 : 2;
+
+template <int DH>
+__global__ __launch_bounds__(256, kFwdWaves<DH>) void attn_core_fwd(const __bf16* __restrict__ qp, const __bf16* __restrict__ kp,
                                                      const __bf16* __restrict__ vt, const int32_t* __restrict__ tok,
                                                      const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
                                                      const int32_t* __restrict__ win_tile0, const int2* __restrict__ tile_item,

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
 
 // ------------------------------------------------------------------ backward, pass KV: dk, dv
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_small_bwd_kv(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int ldq, int ldk, int ldv,
                                                          const float* __restrict__ out, const float* __restrict__ dout,
                                                          const float* __restrict__ lse, const int32_t* __restrict__ tok,
