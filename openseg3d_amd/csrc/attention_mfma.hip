@@ -376,6 +376,244 @@ __global__ __launch_bounds__(256, kFwdWaves<DH>) void attn_core_fwd(const __bf16
 }
 
 template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_core_fwd_lds(const __bf16* __restrict__ qp, const __bf16* __restrict__ kp,
+                                                     const __bf16* __restrict__ vt, const int32_t* __restrict__ tok,
+                                                     const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
+                                                     const int32_t* __restrict__ win_tile0, const int2* __restrict__ tile_item,
+                                                     int n_items, int heads, int64_t mpad, float* __restrict__ out,
+                                                     float* __restrict__ lse) {
+    constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
+    // One workgroup = four consecutive 32-query tiles of ONE window and one head: the K / V fragments of every key tile
+    // are brought in once per workgroup (two 16-B loads per thread), parked in LDS in fragment order and read from there
+    // by the four waves (conflict-free ds_read_b128) -- a quarter of the L1 fragment traffic of attn_core_fwd.  The grid
+    // has one workgroup per tile; those whose tile is not the first of a group of four have nothing to do.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int2 item0 = tile_item[blockIdx.x];
+    if (item0.y & 3) return;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int n = win_count[item0.x], start = win_start[item0.x];
+    const int64_t pos0 = (int64_t)win_tile0[item0.x] * 32;
+    const int n_kt = (n + 31) >> 5;
+    const int q0 = (item0.y + wave) * 32;
+    const bool active = q0 < n;            // this wave's query tile exists (wave-uniform)
+    const bool two = n - q0 > 16;  // the tile's second 16-query group exists (wave-uniform)
+    (void)n_items;
+    const int64_t qk_half = mpad * heads * DHS;
+    const int64_t vt_half = (int64_t)heads * DH * mpad;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // lane byte offsets; channel slices / d rows that do not exist read slice 0 / row 0
+    uint32_t koff[2][KS], qoff[2][KS], voff[NB];
+    bool slice_ok[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        slice_ok[s] = 32 * s + 8 * g < DHS;
+        const int sl = slice_ok[s] ? 32 * s + 8 * g : 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            koff[u][s] = (uint32_t)(((u * 16 + c16) * heads * DHS + sl) * 2);
+            qoff[u][s] = (uint32_t)(((q0 + u * 16 + c16) * heads * DHS + sl) * 2);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) voff[b] = (uint32_t)(((int64_t)(16 * b + c16 < DH ? 16 * b + c16 : 0) * mpad + 8 * g) * 2);
+    const int64_t kstep = (int64_t)32 * heads * DHS * 2;
+    // token rows of this lane's two queries
+    int32_t token[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) token[j] = q0 + 16 * j + c16 < n ? tok[start + q0 + 16 * j + c16] : -1;
+
+    // LDS image of one key tile, double buffered: piece p = 64 lanes x 16 B in register-fragment order
+    constexpr int kKPieces = 2 * KS * 2, kVPieces = NB * 2, kPieces = kKPieces + kVPieces;
+    constexpr int kMine = (kPieces * 64 + 255) / 256;  // 16-B items per thread
+    __shared__ u32x4 tile_lds[2][kPieces * 64];
+    u32x4 kf[1][2][KS][2], vf[1][NB][2];
+    u32x4 st_reg[kMine];
+    auto stage_load = [&](int h, int t) {
+        const char* kb = reinterpret_cast<const char*>(kp + (pos0 * heads + h) * DHS) + t * kstep;
+        const char* vb = reinterpret_cast<const char*>(vt + (int64_t)h * DH * mpad + pos0) + t * 64;
+#pragma unroll
+        for (int j = 0; j < kMine; ++j) {
+            const int item = j * 256 + threadIdx.x;
+            const int piece = item >> 6, l = item & 63, lg = l >> 4, lc = l & 15;
+            st_reg[j] = zero4;
+            if (piece < kKPieces) {  // K piece (u, s, plane)
+                const int plane = piece & 1, us = piece >> 1, s_ = us % KS, u = us / KS;
+                const int sl = 32 * s_ + 8 * lg < DHS ? 32 * s_ + 8 * lg : 0;
+                st_reg[j] = *reinterpret_cast<const u32x4*>(kb + plane * (qk_half * 2) + (uint32_t)(((u * 16 + lc) * heads * DHS + sl) * 2));
+            } else if (piece < kPieces) {  // V piece (b, plane)
+                const int pv = piece - kKPieces, plane = pv & 1, b_ = pv >> 1;
+                const int64_t row = 16 * b_ + lc < DH ? 16 * b_ + lc : 0;
+                st_reg[j] = *reinterpret_cast<const u32x4*>(vb + plane * (vt_half * 2) + (row * mpad + 8 * lg) * 2);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < kMine; ++j) {
+            const int item = j * 256 + threadIdx.x;
+            if (kPieces * 64 % 256 == 0 || item < kPieces * 64) tile_lds[buf][item] = st_reg[j];
+        }
+    };
+    auto fetch = [&](int buf) {  // this wave's fragments of the staged tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                kf[0][u][s][0] = tile_lds[buf][((u * KS + s) * 2 + 0) * 64 + lane];
+                kf[0][u][s][1] = tile_lds[buf][((u * KS + s) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            vf[0][b][0] = tile_lds[buf][(kKPieces + b * 2 + 0) * 64 + lane];
+            vf[0][b][1] = tile_lds[buf][(kKPieces + b * 2 + 1) * 64 + lane];
+        }
+    };
+    // Q fragments of the two query groups: B operand, lane (query c16, channels 32s + 8g .. +7)
+    u32x4 qf[2][KS][2];
+    auto load_q = [&](int h) {
+        const char* qb = reinterpret_cast<const char*>(qp + (pos0 * heads + h) * DHS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(qb + qoff[j][s]);
+                const u32x4 b = *reinterpret_cast<const u32x4*>(qb + qk_half * 2 + qoff[j][s]);
+                qf[j][s][0] = slice_ok[s] ? a : zero4;
+                qf[j][s][1] = slice_ok[s] ? b : zero4;
+            }
+    };
+
+    f32x4 o_acc[2][NB];
+    float m_run[2], l_run[2];
+    auto reset = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            m_run[j] = -INFINITY;
+            l_run[j] = 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) o_acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // one key tile for query group j: scores, online softmax, O^T += V^T . P
+    auto group_tile = [&](int j, int t, auto stage, bool last, f32x4 (&s_acc)[2]) {
+        constexpr int S = decltype(stage)::value;
+        float sc[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[u * 4 + r] = s_acc[u][r];
+        if (last) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, SEG3D_WAVE));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, SEG3D_WAVE));
+        const float m_new = fmaxf(m_run[j], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_new);
+            psum += sc[i];
+        }
+        psum += __shfl_xor(psum, 16, SEG3D_WAVE);
+        psum += __shfl_xor(psum, 32, SEG3D_WAVE);
+        l_run[j] = fmaf(l_run[j], alpha, psum);
+        m_run[j] = m_new;
+        u32x4 ph, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = pack_bf16(sc[2 * i], sc[2 * i + 1]);
+            const float h0 = __builtin_bit_cast(float, w << 16);
+            const float h1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+            ph[i] = w;
+            pl[i] = pack_bf16(sc[2 * i] - h0, sc[2 * i + 1] - h1);
+        }
+        const bf16x8 p_hi = __builtin_bit_cast(bf16x8, ph), p_lo = __builtin_bit_cast(bf16x8, pl);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const bf16x8 v_hi = __builtin_bit_cast(bf16x8, vf[S][b][0]), v_lo = __builtin_bit_cast(bf16x8, vf[S][b][1]);
+            f32x4 acc = o_acc[j][b] * alpha;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_lo, p_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_hi, acc, 0, 0, 0);
+            o_acc[j][b] = acc;
+        }
+    };
+    auto scores = [&](int j, auto stage, f32x4 (&s_acc)[2]) {
+        constexpr int S = decltype(stage)::value;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            s_acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 k_hi = __builtin_bit_cast(bf16x8, kf[S][u][s][0]);
+                const bf16x8 k_lo = __builtin_bit_cast(bf16x8, kf[S][u][s][1]);
+                const bf16x8 q_hi = __builtin_bit_cast(bf16x8, qf[j][s][0]);
+                const bf16x8 q_lo = __builtin_bit_cast(bf16x8, qf[j][s][1]);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_lo, q_hi, s_acc[u], 0, 0, 0);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_lo, s_acc[u], 0, 0, 0);
+                s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, q_hi, s_acc[u], 0, 0, 0);
+            }
+        }
+    };
+    // epilogue of a head: O^T[d = 16b + 4g + r][query c16] / l  ->  out[token][h*DH + d]
+    auto finish = [&](int h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (token[j] < 0) continue;
+            const float inv = 1.0f / l_run[j];
+            float* op = out + (int64_t)token[j] * (heads * DH) + h * DH;
+            // a lane's 4 accumulator rows are 4 consecutive channels of its query: one 16-B store (8-B for DH = 6)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int d = 16 * b + 4 * g;
+                const f32x4 o = o_acc[j][b] * inv;
+                if (DH % 4 == 0) {
+                    if (d < DH) *reinterpret_cast<f32x4*>(op + d) = o;
+                } else {
+                    if (d + 1 < DH) *reinterpret_cast<f32x2*>(op + d) = (f32x2){o[0], o[1]};
+                    if (d + 3 < DH) *reinterpret_cast<f32x2*>(op + d + 2) = (f32x2){o[2], o[3]};
+                }
+            }
+            if (lse && g == 0) lse[(int64_t)token[j] * heads + h] = (m_run[j] + __builtin_amdgcn_logf(l_run[j])) * kLn2;
+        }
+    };
+    auto step = [&](int h, int t, auto stage) {
+        const bool last = t + 1 == n_kt;
+        f32x4 s0[2], s1[2];
+        scores(0, stage, s0);
+        if (two) scores(1, stage, s1);
+        group_tile(0, t, stage, last, s0);
+        if (two) group_tile(1, t, stage, last, s1);
+        if (last) finish(h);
+    };
+
+    using St0 = std::integral_constant<int, 0>;
+    const int h = blockIdx.y;
+    reset();
+    if (active) load_q(h);
+    stage_load(h, 0);
+    stage_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < n_kt; ++t) {
+        const bool more = t + 1 < n_kt;
+        if (more) stage_load(h, t + 1);  // in flight while this tile is multiplied
+        if (active) {
+            fetch(buf);
+            step(h, t, St0{});
+        }
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+template <int DH>
 size_t prepared_bytes(int64_t mpad, int heads) {
     const size_t qk = (size_t)mpad * heads * Geo<DH>::DHS * 2 * sizeof(__bf16);  // hi + lo
     const size_t vt = (size_t)heads * DH * mpad * 2 * sizeof(__bf16);
@@ -400,8 +638,15 @@ int run_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     SEG3D_CHECK_LAUNCH();
     (void)qg_item;
     (void)n_qg;
-    hipLaunchKernelGGL(attn_core_fwd<DH>, dim3((unsigned)((n_tiles + 3) / 4), (unsigned)heads), dim3(256), 0, st, qp, kp, vt, tok, win_start,
-                       win_count, win_tile0, tile_item, n_tiles, heads, mpad, out, lse);
+    // default: K / V tiles staged once per four query tiles through LDS (dh 24: 152 -> 120 us per layer on the headline
+    // scene, dh 48: 90 -> 83 us); SEG3D_ATTN_LDS=0 selects the wave-independent kernel for A/B runs
+    static const int lds_env = getenv("SEG3D_ATTN_LDS") ? atoi(getenv("SEG3D_ATTN_LDS")) : 1;
+    if (lds_env)
+        hipLaunchKernelGGL(attn_core_fwd_lds<DH>, dim3((unsigned)n_tiles, (unsigned)heads), dim3(256), 0, st, qp, kp, vt, tok,
+                           win_start, win_count, win_tile0, tile_item, n_tiles, heads, mpad, out, lse);
+    else
+        hipLaunchKernelGGL(attn_core_fwd<DH>, dim3((unsigned)((n_tiles + 3) / 4), (unsigned)heads), dim3(256), 0, st, qp, kp, vt, tok, win_start,
+                           win_count, win_tile0, tile_item, n_tiles, heads, mpad, out, lse);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
