@@ -368,6 +368,188 @@ __global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q(BwdWs<DH> ws, 
     if (lane == 0) *tau_slot = tau[0] > tau_min ? -tau_sum * kLn2 / tau_c : 0.f;  // one plain store per wave: no atomics
 }
 
+template <int DH>
+__global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q_lds(BwdWs<DH> ws, const float* __restrict__ q, int ldq,
+                                                  const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
+                                                  const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
+                                                  const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
+                                                  const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
+                                                  int lddq) {
+    constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
+    // One workgroup = four consecutive 32-query tiles of ONE window and one head (see attn_core_fwd_lds): the streamed
+    // K, V and K^T fragments of a key tile are loaded once per workgroup and shared through LDS.  Grid: one workgroup
+    // per tile, those whose tile is not the first of a group of four return at once.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int2 item0 = tile_item[blockIdx.x];
+    if (item0.y & 3) return;
+    const int h = blockIdx.y, g = lane >> 4, c16 = lane & 15;
+    const int n = win_count[item0.x], start = win_start[item0.x];
+    const int64_t pos0 = (int64_t)win_tile0[item0.x] * 32;
+    const int n_kt = (n + 31) >> 5;
+    const int q0 = (item0.y + wave) * 32;
+    const bool active = q0 < n;  // this wave's query tile exists (wave-uniform); its tile index is blockIdx.x + wave
+    float* tau_slot = ws.tau_part + (size_t)blockIdx.y * n_items + blockIdx.x + wave;
+    const bool two = n - q0 > 16;
+    const int64_t row_half = mpad * heads * DHS * 2, tr_half = (int64_t)heads * DH * mpad * 2;  // bytes
+    const Lanes<DH> L(g, c16, heads, mpad);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const bf16x8 zf = __builtin_bit_cast(bf16x8, zero4);
+
+    // stationary: Q and dO fragments of the two query groups (B operands), LSE and delta of the lane's queries
+    bf16x8 q_hi[2][KS], q_lo[2][KS], g_hi[2][KS], g_lo[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) q_hi[j][s] = q_lo[j][s] = g_hi[j][s] = g_lo[j][s] = zf;
+    float lq[2] = {0.f, 0.f}, dl[2] = {0.f, 0.f};
+    if (active) {
+        const char* qb = reinterpret_cast<const char*>(ws.qp + ((pos0 + q0) * heads + h) * DHS);
+        const char* gb = reinterpret_cast<const char*>(ws.gp + ((pos0 + q0) * heads + h) * DHS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                ld2(qb, row_half, L.row[j][s], &q_hi[j][s], &q_lo[j][s]);
+                ld2(gb, row_half, L.row[j][s], &g_hi[j][s], &g_lo[j][s]);
+                if (!L.slice_ok[s]) q_hi[j][s] = q_lo[j][s] = g_hi[j][s] = g_lo[j][s] = zf;
+            }
+            lq[j] = ws.lp[(int64_t)h * mpad + pos0 + q0 + 16 * j + c16];
+            dl[j] = ws.dp[(int64_t)h * mpad + pos0 + q0 + 16 * j + c16];
+        }
+    }
+    f32x4 acc[2][NB];
+    float tau_acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t kstep = (int64_t)32 * heads * DHS * 2;
+    const char* kb = reinterpret_cast<const char*>(ws.kp + (pos0 * heads + h) * DHS);
+    const char* vb = reinterpret_cast<const char*>(ws.vp + (pos0 * heads + h) * DHS);
+    const char* ktb = reinterpret_cast<const char*>(ws.kt + (int64_t)h * DH * mpad + pos0);
+    // LDS image of one key tile: fragment f (hi, lo) = pieces 2f, 2f + 1; K rows: f = u * KS + s, V rows: 2 KS + u * KS + s,
+    // K^T: 4 KS + b; a piece = 64 lanes x 16 B in register order
+    constexpr int kFrags = 4 * KS + NB, kPieces = 2 * kFrags, kMine = (kPieces * 64 + 255) / 256;
+    __shared__ u32x4 tile_lds[2][kPieces * 64];
+    u32x4 st_reg[kMine];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int jj = 0; jj < kMine; ++jj) {
+            const int item = jj * 256 + threadIdx.x;
+            const int piece = item >> 6, l = item & 63, lg = l >> 4, lc = l & 15;
+            const int f = piece >> 1, plane = piece & 1;
+            st_reg[jj] = zero4;
+            if (f < 4 * KS) {  // row-major K (f < 2 KS) or V fragment of streamed token 16 u + lc, slice s
+                const int fr = f < 2 * KS ? f : f - 2 * KS, u = fr / KS, s_ = fr % KS;
+                const int sl = 32 * s_ + 8 * lg < DHS ? 32 * s_ + 8 * lg : 0;
+                const char* base = (f < 2 * KS ? kb : vb) + t * kstep + plane * row_half;
+                st_reg[jj] = *reinterpret_cast<const u32x4*>(base + (uint32_t)(((u * 16 + lc) * heads * DHS + sl) * 2));
+            } else if (f < kFrags) {  // transposed K fragment: row d = 16 b + lc, token slots 8 lg .. 8 lg + 7
+                const int b_ = f - 4 * KS;
+                const int64_t row = 16 * b_ + lc < DH ? 16 * b_ + lc : 0;
+                st_reg[jj] = *reinterpret_cast<const u32x4*>(ktb + t * 64 + plane * tr_half + (row * mpad + 8 * lg) * 2);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int jj = 0; jj < kMine; ++jj) {
+            const int item = jj * 256 + threadIdx.x;
+            if (kPieces * 64 % 256 == 0 || item < kPieces * 64) tile_lds[buf][item] = st_reg[jj];
+        }
+    };
+    auto frag = [&](int buf, int f, bf16x8* hi, bf16x8* lo) {
+        *hi = __builtin_bit_cast(bf16x8, tile_lds[buf][(2 * f) * 64 + lane]);
+        *lo = __builtin_bit_cast(bf16x8, tile_lds[buf][(2 * f + 1) * 64 + lane]);
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < n_kt; ++t) {
+        const bool last = t + 1 == n_kt;
+        if (!last) stage_load(t + 1);  // in flight while this tile is multiplied
+        bf16x8 k_hi[2][KS], k_lo[2][KS], v_hi[2][KS], v_lo[2][KS], kt_hi[NB], kt_lo[NB];
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    frag(buf, u * KS + s, &k_hi[u][s], &k_lo[u][s]);
+                    frag(buf, 2 * KS + u * KS + s, &v_hi[u][s], &v_lo[u][s]);
+                }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) frag(buf, 4 * KS + b, &kt_hi[b], &kt_lo[b]);
+        }
+        auto group = [&](int j) {
+            float dsv[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    s_acc = mfma3(k_hi[u][s], k_lo[u][s], q_hi[j][s], q_lo[j][s], s_acc);  // S^T[key][query]
+                    p_acc = mfma3(v_hi[u][s], v_lo[u][s], g_hi[j][s], g_lo[j][s], p_acc);  // dP^T[key][query]
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[j]);
+                    if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;
+                    const float ds = p * (p_acc[r] - dl[j]);
+                    dsv[u * 4 + r] = ds;
+                    tau_acc[j] = fmaf(ds, s_acc[r], tau_acc[j]);
+                }
+            }
+            bf16x8 ds_hi, ds_lo;
+            split_frag(dsv, &ds_hi, &ds_lo);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[j][b] = mfma3(kt_hi[b], kt_lo[b], ds_hi, ds_lo, acc[j][b]);  // dQhat^T[d][query] * tau_c
+        };
+        if (active) {
+            group(0);
+            if (two) group(1);
+        }
+        if (!last) stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (!active) return;  // no barrier below
+
+    const float tau_c = fmaxf(tau[0], tau_min);
+    const float inv_tau = 1.0f / tau_c;
+    float tau_sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const int qi = q0 + 16 * j + c16;
+        const bool valid = qi < n;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[j][b] = acc[j][b] * inv_tau;
+        if (valid) tau_sum += tau_acc[j];
+        // every lane of a query column takes part in the shuffles; invalid columns read row 0 and store nothing
+        const int32_t token = tok[start + (valid ? qi : 0)];
+        through_normalise<DH>(q + (int64_t)token * ldq + h * DH, g, acc[j]);
+        if (valid) {
+            float* o = dq + (int64_t)token * lddq + h * DH;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int d = 16 * b + 4 * g;
+                if (DH % 4 == 0) {
+                    if (d < DH) *reinterpret_cast<f32x4*>(o + d) = acc[j][b];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (d + r < DH) o[d + r] = acc[j][b][r];
+                }
+            }
+        }
+    }
+    // d/dtau: s_nat = s2 * ln2 = c / tau  ->  dL/dtau = -sum(ds * s_nat) / tau   (zero while tau is clamped)
+    for (int off = 32; off > 0; off >>= 1) tau_sum += __shfl_xor(tau_sum, off, SEG3D_WAVE);
+    if (lane == 0) *tau_slot = tau[0] > tau_min ? -tau_sum * kLn2 / tau_c : 0.f;  // one plain store per wave: no atomics
+}
+
 // dtau = sum of the per-wave partials in a fixed order
 __global__ __launch_bounds__(1024) void tau_reduce(const float* __restrict__ part, int count, float* __restrict__ dtau) {
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;  // independent chains: loads overlap
@@ -528,6 +710,197 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(BwdWs<DH> ws, const float* __
 }
 
 template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_lds(BwdWs<DH> ws, const float* __restrict__ k, int ldk,
+                                                   const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
+                                                   const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
+                                                   const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
+                                                   float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+    constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
+    // One workgroup = four consecutive 32-key tiles of ONE window and one head; the streamed Q, dO, Q^T, dO^T fragments
+    // of a query tile are loaded once per workgroup and shared through LDS (see attn_core_fwd_lds).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int2 item0 = tile_item[blockIdx.x];
+    if (item0.y & 3) return;
+    (void)n_items;
+    const int h = blockIdx.y, g = lane >> 4, c16 = lane & 15;
+    const int n = win_count[item0.x], start = win_start[item0.x];
+    const int64_t pos0 = (int64_t)win_tile0[item0.x] * 32;
+    const int n_qt = (n + 31) >> 5;
+    const int k0 = (item0.y + wave) * 32;
+    const bool active = k0 < n;  // this wave's key tile exists (wave-uniform)
+    const bool two = n - k0 > 16;
+    const int64_t row_half = mpad * heads * DHS * 2, tr_half = (int64_t)heads * DH * mpad * 2;  // bytes
+    const Lanes<DH> L(g, c16, heads, mpad);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const bf16x8 zf = __builtin_bit_cast(bf16x8, zero4);
+
+    // stationary: K and V fragments of the two key groups: B operands (k = channel, column = key)
+    bf16x8 k_hi[2][KS], k_lo[2][KS], v_hi[2][KS], v_lo[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) k_hi[j][s] = k_lo[j][s] = v_hi[j][s] = v_lo[j][s] = zf;
+    if (active) {
+        const char* kb = reinterpret_cast<const char*>(ws.kp + ((pos0 + k0) * heads + h) * DHS);
+        const char* vb = reinterpret_cast<const char*>(ws.vp + ((pos0 + k0) * heads + h) * DHS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                ld2(kb, row_half, L.row[j][s], &k_hi[j][s], &k_lo[j][s]);
+                ld2(vb, row_half, L.row[j][s], &v_hi[j][s], &v_lo[j][s]);
+                if (!L.slice_ok[s]) k_hi[j][s] = k_lo[j][s] = v_hi[j][s] = v_lo[j][s] = zf;
+            }
+    }
+    f32x4 dk_acc[2][NB], dv_acc[2][NB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            dk_acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv_acc[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    const int64_t qstep = (int64_t)32 * heads * DHS * 2;
+    const char* qb = reinterpret_cast<const char*>(ws.qp + (pos0 * heads + h) * DHS);
+    const char* gb = reinterpret_cast<const char*>(ws.gp + (pos0 * heads + h) * DHS);
+    const char* qtb = reinterpret_cast<const char*>(ws.qt + (int64_t)h * DH * mpad + pos0);
+    const char* gtb = reinterpret_cast<const char*>(ws.gt + (int64_t)h * DH * mpad + pos0);
+    const float* lpb = ws.lp + (int64_t)h * mpad + pos0 + 4 * g;  // + 32 t + 16 u: the accumulator's 4 query rows
+    const float* dpb = ws.dp + (int64_t)h * mpad + pos0 + 4 * g;
+    // LDS image of one query tile: fragment f (hi, lo) = pieces 2f, 2f + 1; Q rows: f = u * KS + s, dO rows: 2 KS + ..,
+    // Q^T: 4 KS + b, dO^T: 4 KS + NB + b; LSE / delta (8 floats per lane) stay direct loads
+    constexpr int kFrags = 4 * KS + 2 * NB, kPieces = 2 * kFrags, kMine = (kPieces * 64 + 255) / 256;
+    __shared__ u32x4 tile_lds[2][kPieces * 64];
+    u32x4 st_reg[kMine];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int jj = 0; jj < kMine; ++jj) {
+            const int item = jj * 256 + threadIdx.x;
+            const int piece = item >> 6, l = item & 63, lg = l >> 4, lc = l & 15;
+            const int f = piece >> 1, plane = piece & 1;
+            st_reg[jj] = zero4;
+            if (f < 4 * KS) {  // row-major Q (f < 2 KS) or dO fragment of streamed token 16 u + lc, slice s
+                const int fr = f < 2 * KS ? f : f - 2 * KS, u = fr / KS, s_ = fr % KS;
+                const int sl = 32 * s_ + 8 * lg < DHS ? 32 * s_ + 8 * lg : 0;
+                const char* base = (f < 2 * KS ? qb : gb) + t * qstep + plane * row_half;
+                st_reg[jj] = *reinterpret_cast<const u32x4*>(base + (uint32_t)(((u * 16 + lc) * heads * DHS + sl) * 2));
+            } else if (f < kFrags) {  // transposed Q (f < 4 KS + NB) or dO fragment: row d = 16 b + lc, token slots 8 lg ..
+                const int fb = f - 4 * KS, b_ = fb < NB ? fb : fb - NB;
+                const int64_t row = 16 * b_ + lc < DH ? 16 * b_ + lc : 0;
+                const char* base = (fb < NB ? qtb : gtb) + t * 64 + plane * tr_half;
+                st_reg[jj] = *reinterpret_cast<const u32x4*>(base + (row * mpad + 8 * lg) * 2);
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int jj = 0; jj < kMine; ++jj) {
+            const int item = jj * 256 + threadIdx.x;
+            if (kPieces * 64 % 256 == 0 || item < kPieces * 64) tile_lds[buf][item] = st_reg[jj];
+        }
+    };
+    auto frag = [&](int buf, int f, bf16x8* hi, bf16x8* lo) {
+        *hi = __builtin_bit_cast(bf16x8, tile_lds[buf][(2 * f) * 64 + lane]);
+        *lo = __builtin_bit_cast(bf16x8, tile_lds[buf][(2 * f + 1) * 64 + lane]);
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < n_qt; ++t) {
+        const bool last = t + 1 == n_qt;
+        if (!last) stage_load(t + 1);  // in flight while this tile is multiplied
+        bf16x8 q_hi[2][KS], q_lo[2][KS], g_hi[2][KS], g_lo[2][KS], qt_hi[NB], qt_lo[NB], gt_hi[NB], gt_lo[NB];
+        f32x4 lq[2], dl[2];
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    frag(buf, u * KS + s, &q_hi[u][s], &q_lo[u][s]);
+                    frag(buf, 2 * KS + u * KS + s, &g_hi[u][s], &g_lo[u][s]);
+                }
+                lq[u] = *reinterpret_cast<const f32x4*>(lpb + t * 32 + u * 16);
+                dl[u] = *reinterpret_cast<const f32x4*>(dpb + t * 32 + u * 16);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                frag(buf, 4 * KS + b, &qt_hi[b], &qt_lo[b]);
+                frag(buf, 4 * KS + NB + b, &gt_hi[b], &gt_lo[b]);
+            }
+        }
+        auto group = [&](int j) {
+            float pv[8], dsv[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    s_acc = mfma3(q_hi[u][s], q_lo[u][s], k_hi[j][s], k_lo[j][s], s_acc);  // S[query][key]
+                    p_acc = mfma3(g_hi[u][s], g_lo[u][s], v_hi[j][s], v_lo[j][s], p_acc);  // dP[query][key]
+                }
+                // rows of this accumulator: queries 32t + 16u + 4g + r (4 consecutive positions)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[u][r]);
+                    if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;
+                    pv[u * 4 + r] = p;
+                    dsv[u * 4 + r] = p * (p_acc[r] - dl[u][r]);
+                }
+            }
+            bf16x8 p_hi, p_lo, ds_hi, ds_lo;
+            split_frag(pv, &p_hi, &p_lo);
+            split_frag(dsv, &ds_hi, &ds_lo);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                dv_acc[j][b] = mfma3(gt_hi[b], gt_lo[b], p_hi, p_lo, dv_acc[j][b]);    // dV^T[d][key]
+                dk_acc[j][b] = mfma3(qt_hi[b], qt_lo[b], ds_hi, ds_lo, dk_acc[j][b]);  // dKhat^T[d][key] / ln2
+            }
+        };
+        if (active) {
+            group(0);
+            if (two) group(1);
+        }
+        if (!last) stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (!active) return;  // no barrier below
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const int ki = k0 + 16 * j + c16;
+        const bool valid = ki < n;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dk_acc[j][b] = dk_acc[j][b] * kLn2;  // Q~ = q_hat * log2e / tau  ->  q_hat / tau = Q~ * ln2
+        const int32_t token = tok[start + (valid ? ki : 0)];
+        through_normalise<DH>(k + (int64_t)token * ldk + h * DH, g, dk_acc[j]);
+        if (valid) {
+            float* ok_ = dk + (int64_t)token * lddk + h * DH;
+            float* ov = dv + (int64_t)token * lddv + h * DH;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int d = 16 * b + 4 * g;
+                if (DH % 4 == 0) {
+                    if (d < DH) {
+                        *reinterpret_cast<f32x4*>(ok_ + d) = dk_acc[j][b];
+                        *reinterpret_cast<f32x4*>(ov + d) = dv_acc[j][b];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (d + r < DH) {
+                            ok_[d + r] = dk_acc[j][b][r];
+                            ov[d + r] = dv_acc[j][b][r];
+                        }
+                }
+            }
+        }
+    }
+}
+
+template <int DH>
 int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out, const float* dout,
             const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
             const int32_t* win_tile0, const int2* tile_item, int n_tiles, const int2* qg_item, int n_qg, int heads,
@@ -542,6 +915,28 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     SEG3D_CHECK_LAUNCH();
     (void)qg_item;
     (void)n_qg;
+    // default: the streamed fragments of a tile are staged once per four stationary tiles through LDS (headline scene, per
+    // layer: pass A 276 -> 208 us at dh 24, 169 -> 141 us at dh 48; pass B 328 -> 305 us at dh 24);
+    // SEG3D_ATTN_LDS=0 selects the wave-independent kernels for A/B runs
+    static const int lds_env = getenv("SEG3D_ATTN_LDS") ? atoi(getenv("SEG3D_ATTN_LDS")) : 1;
+    if (lds_env) {
+        dim3 grid((unsigned)n_tiles, (unsigned)heads);
+        hipLaunchKernelGGL(attn_bwd_q_lds<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0,
+                           tile_item, n_tiles, heads, mpad, tau, tau_min, dq, lddq);
+        SEG3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(1024), 0, st, ws.tau_part, (int)(n_tiles * heads), dtau);
+        SEG3D_CHECK_LAUNCH();
+        if (DH <= 24) {
+            hipLaunchKernelGGL(attn_bwd_kv_lds<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0,
+                               tile_item, n_tiles, heads, mpad, dk, lddk, dv, lddv);
+        } else {  // dh 48: one wave per SIMD either way, and the 56 KiB LDS image costs more than it saves (211 vs 229 us)
+            dim3 grid4((unsigned)((n_tiles + 3) / 4), (unsigned)heads);
+            hipLaunchKernelGGL(attn_bwd_kv<DH>, grid4, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0,
+                               tile_item, n_tiles, heads, mpad, dk, lddk, dv, lddv);
+        }
+        SEG3D_CHECK_LAUNCH();
+        return SEG3D_OK;
+    }
     dim3 grid((unsigned)((n_tiles + 3) / 4), (unsigned)heads);
     hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, tile_item,
                        n_tiles, heads, mpad, tau, tau_min, dq, lddq);
