@@ -569,6 +569,32 @@ class _BatchNormActFn(torch.autograd.Function):
         return dx, dres, sums[1], sums[0], None, None, None, None, None
 
 
+def narrow_batch_norm(x, bn):
+    """Training-mode BatchNorm1d over [rows, C] with C not a multiple of 4 (the raw 6 / 8 point channels): the rows and
+    the affine parameters are zero-padded to the next multiple of 4 and run through the same statistics / affine /
+    backward kernels as the wide layers; the running buffers are updated from the kernel's shifted sums."""
+    m, c = x.shape
+    pad = (-c) % 4
+    xp = torch.nn.functional.pad(_f32c(x), (0, pad))
+    w = torch.nn.functional.pad(bn.weight, (0, pad), value=1.0)
+    b = torch.nn.functional.pad(bn.bias, (0, pad))
+    cp = c + pad
+    with torch.no_grad():
+        stats = torch.empty((6, cp), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, cp)
+        ws = _workspace(ws_bytes, x.device)
+        _lib.call("seg3d_batchnorm_stats", _ptr(xp), m, cp, float(bn.eps), _ptr(w), _ptr(b), 0.0, None, None, _ptr(stats),
+                  _ptr(ws), ws_bytes, _stream())
+        bn.num_batches_tracked += 1
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        d = stats[0, :c] / m  # mean of (x - x[0]); biased variance from the shifted sums, as the kernel forms it
+        var = (stats[1, :c] / m - d * d).clamp_(min=0.0)
+        bn.running_mean.mul_(1 - mom).add_(stats[2, :c], alpha=mom)
+        bn.running_var.mul_(1 - mom).add_(var, alpha=mom * (m / max(m - 1, 1)))
+    y = _BatchNormActFn.apply(xp, None, w, b, stats[2], stats[3], stats[4], stats[5], False)
+    return y[:, :c]
+
+
 def bn_eval_affine(bn):
     """(scale, shift, key) with bn(x) = x * scale + shift in eval mode.  Cached on the module, keyed on the tensors'
     versions so that loading a checkpoint invalidates it; training steps reset it (batch_norm_act) because the kernel

@@ -133,6 +133,36 @@ def test_batchnorm_act_training_and_eval(m, c, relu, with_res):
     assert float((ye.cpu().double() - yre).abs().max()) < 5e-5
 
 
+@pytest.mark.parametrize("m,c", [(50001, 6), (3000, 8), (777, 10)])
+def test_narrow_batchnorm_matches_torch(m, c):
+    """The input BatchNorm of the point encoder (6 / 8 raw channels): padded rows through the library kernels vs
+    nn.BatchNorm1d in fp64 -- output, parameter gradients, input gradient, running buffers."""
+    from openseg3d_amd.segformer import NarrowBatchNorm1d
+    dev = torch.device("cuda:0")
+    torch.manual_seed(c)
+    x = torch.randn(m, c) * torch.tensor([30.0, 30.0, 2.0, 1.0, 0.3, 0.1, 5.0, 1.0, 1.0, 1.0][:c]) + 3.0
+    g = torch.randn(m, c)
+    bn = NarrowBatchNorm1d(c).to(dev).train()
+    ref = nn.BatchNorm1d(c).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(c)), bn.bias.copy_(0.1 * torch.randn(c))
+        ref.weight.copy_(bn.weight.cpu().double()), ref.bias.copy_(bn.bias.cpu().double())
+    xr = x.double().requires_grad_()
+    yr = ref(xr)
+    yr.backward(g.double())
+    xg = x.to(dev).requires_grad_()
+    y = bn(xg)
+    y.backward(g.to(dev))
+    assert y.shape == (m, c)
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 5e-5
+    assert float((xg.grad.cpu().double() - xr.grad).abs().max()) < 5e-5
+    for got, want in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
+        assert float((got.cpu().double() - want).abs().max()) < 1e-3 * max(1.0, float(want.abs().max()))
+    assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) < 1e-4
+    assert float((bn.running_var.cpu().double() - ref.running_var).abs().max()) < 1e-3 * float(ref.running_var.max())
+    assert int(bn.num_batches_tracked) == 1
+
+
 def test_eval_batchnorm_fold_follows_training_and_checkpoint_loads():
     """The cached eval-mode affine (scale, shift) must track the running statistics: after training steps (buffers
     updated by the kernel through raw pointers) and after load_state_dict."""
