@@ -183,19 +183,25 @@ class PointTransformer(nn.Module):
 
     def prepare(self, batch_dict):
         """Index plan of the whole backbone -- site levels, rulebooks, row orders, window plans of the four stages --
-        built before any feature kernel is queued.  All 7 host read-backs of a forward (3 strided levels, 4 window
-        plans) happen here, while only short index kernels are in flight; afterwards the feature pipeline (forward,
+        built before any feature kernel is queued.  All 4 host read-backs of a forward (3 strided levels, then the window
+        counts of all four stages at once) happen here, while only short index kernels are in flight; afterwards the feature pipeline (forward,
         loss, backward) is enqueued without a single wait, so the host runs ahead of the GPU instead of draining the
         queue once per stage."""
         level = spconv.SiteLevel(batch_dict["voxel_coords"].int(), self.sparse_shape, batch_dict["batch_size"])
         batch_dict["site_level"] = level
         widths = (48, 96, 192, 384)
+        launched = []
         for k in range(4):
             level.subm()
-            getattr(self, f"swformer_block{k + 1}")[0].plan_level(level, widths[k])
+            part = getattr(self, f"swformer_block{k + 1}")[0]
+            if part not in level.window_plans:  # partition kernels queued now, counts of all stages read back once below
+                level.window_plans[part] = part.launch_plan(level.coords, level.batch_size, widths[k])
+                launched.append(level.window_plans[part])
             if k < 3:
                 level.parity_order()
                 level = level.down()[0]
+        if launched:
+            SparseWindowPartitionLayer.finish_plans(launched)
         return batch_dict
 
     def forward(self, batch_dict):

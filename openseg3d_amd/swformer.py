@@ -82,7 +82,9 @@ class SparseWindowPartitionLayer(nn.Module):
         return self._inv_freq[key]
 
     @torch.no_grad()
-    def plan(self, coords, batch_size, feat_dim, want_debug=False):
+    def launch_plan(self, coords, batch_size, feat_dim, want_debug=False):
+        """Queue the partition and positional-embedding kernels of both shifts; nothing is read back.  finish_plans()
+        completes one or several launched plans with a single host read-back."""
         if feat_dim % 3 or (feat_dim // 3) % 2:
             raise ValueError("feature dim must be divisible by 6 (point_transformer_layer.py:176,196)")
         index, pos = [], []
@@ -91,14 +93,24 @@ class SparseWindowPartitionLayer(nn.Module):
             wi = ops.window_partition(coords, batch_size, win, nwin, shift, self.levels(), want_debug=want_debug)
             index.append(wi)
             pos.append(ops.pos_embed(wi.in_win, win, self.inv_freq(feat_dim, coords.device), feat_dim))
-        counts = torch.stack([wi.counts for wi in index]).tolist()  # the stage's one host sync
+        return WindowPlan(index, pos)
+
+    @staticmethod
+    @torch.no_grad()
+    def finish_plans(plans):
+        """One host sync for the window / tile counts of all given plans (every stage, both shifts)."""
+        index = [wi for plan in plans for wi in plan.index]
+        counts = torch.stack([wi.counts for wi in index]).tolist()
         for wi, (n_win, n_drop, n_tiles, n_qg) in zip(index, counts):
             wi.n_windows, wi.n_dropped, wi.n_tiles, wi.n_qgroups = int(n_win), int(n_drop), int(n_tiles), int(n_qg)
             if n_drop:
                 raise RuntimeError(
                     f"{n_drop} voxels exceed max_tokens of their batching level: voxel dropping is "
                     "unsupported (it breaks replace_feature in the reference too, SURVEY.md 8 quirk 1)")
-        return WindowPlan(index, pos)
+        return plans
+
+    def plan(self, coords, batch_size, feat_dim, want_debug=False):
+        return self.finish_plans([self.launch_plan(coords, batch_size, feat_dim, want_debug)])[0]
 
     def plan_level(self, level, feat_dim):
         """The plan of a spconv.SiteLevel, cached on the level: the backbone asks for every stage's plan up front
