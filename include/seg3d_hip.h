@@ -103,10 +103,12 @@ int seg3d_rulebook_subm(const int32_t* coords, int64_t m, const int32_t* shape_z
 /* SparseConv3d(k=3, stride=2, padding=1) output sites, ascending (b,z,y,x).
  * shape_out = floor((shape_in + 2 - 3) / 2) + 1.  coords_out must hold cap_out >= min(8*m_in, cells) rows. */
 size_t seg3d_downsample_workspace_bytes(int32_t batch_size, const int32_t* shape_in_zyx /*host[3]*/);
-int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in, int32_t batch_size,
-                            const int32_t* shape_in_zyx /*host[3]*/, int32_t* coords_out,
-                            int64_t cap_out, int32_t* m_out /*device[1]*/, void* workspace,
-                            size_t workspace_bytes, void* stream);
+int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in,
+                            const int32_t* m_in_dev /* or NULL: exact row count on the DEVICE when m_in is only an upper
+                               bound -- lets the three strided levels be chained without reading a count back */,
+                            int32_t batch_size, const int32_t* shape_in_zyx /*host[3]*/, int32_t* coords_out,
+                            int64_t cap_out, int32_t* m_out /*device*/, void* workspace, size_t workspace_bytes,
+                            void* stream);
 /* nbr_fwd[k][o] = fine row at 2*coords_out[o] + k - 1; nbr_inv[k][i] = coarse row o with
  * 2*o + k - 1 == coords_in[i] (the table SparseInverseConv3d reuses under the same indice_key). */
 int seg3d_rulebook_strided(const int32_t* coords_out, int64_t m_out, int64_t m_in,

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -30,7 +30,7 @@ SIGNATURES = {
     "seg3d_coord_hash_build": (ctypes.c_int, [_p, _i64, _p, _p, _sz, _p]),
     "seg3d_rulebook_subm": (ctypes.c_int, [_p, _i64, _p, _p, _sz, _p, _p]),
     "seg3d_downsample_workspace_bytes": (_sz, [_i32, _p]),
-    "seg3d_downsample_coords": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _sz, _p]),
+    "seg3d_downsample_coords": (ctypes.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _p, _p, _sz, _p]),
     "seg3d_rulebook_strided": (ctypes.c_int, [_p, _i64, _i64, _p, _p, _sz, _p, _p, _p]),
     "seg3d_spconv_packed_bytes": (_sz, [_i32, _i32, _i32]),
     "seg3d_spconv_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),

@@ -52,10 +52,11 @@ __global__ __launch_bounds__(kThreads) void subm_table(const int32_t* __restrict
 }
 
 // ---- strided output sites via bitmap
-__global__ __launch_bounds__(kThreads) void down_mark(const int32_t* __restrict__ coords, int64_t m, Shape3 so,
+__global__ __launch_bounds__(kThreads) void down_mark(const int32_t* __restrict__ coords, int64_t m,
+                                                      const int32_t* __restrict__ m_dev, Shape3 so,
                                                       uint32_t* __restrict__ bitmap) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= m) return;
+    if (i >= m || (m_dev && i >= (int64_t)*m_dev)) return;  // m_dev: exact row count still on the device (chained levels)
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     // per dimension: o = (c + 1 - k) / 2 for the k in {0,1,2} that make it integral and in range
     int oz[2], oy[2], ox[2], nz = 0, ny = 0, nx = 0;
@@ -167,9 +168,9 @@ size_t seg3d_downsample_workspace_bytes(int32_t batch_size, const int32_t* shape
     return c.off;
 }
 
-int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in, int32_t batch_size, const int32_t* shape_in_zyx,
-                            int32_t* coords_out, int64_t cap_out, int32_t* m_out, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in, const int32_t* m_in_dev, int32_t batch_size,
+                            const int32_t* shape_in_zyx, int32_t* coords_out, int64_t cap_out, int32_t* m_out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     if (m_in < 0 || batch_size <= 0 || !shape_in_zyx || !coords_out || !m_out || !workspace || cap_out < 0 ||
         (m_in > 0 && !coords_in))
         return SEG3D_EINVAL;
@@ -184,7 +185,7 @@ int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in, int32_t batc
     if (hipMemsetAsync(bitmap, 0, (size_t)nw * 4, st) != hipSuccess) return SEG3D_ELAUNCH;
     if (m_in > 0) {
         hipLaunchKernelGGL(down_mark, dim3((unsigned)ceil_div64(m_in, kThreads)), dim3(kThreads), 0, st, coords_in, m_in,
-                           so, bitmap);
+                           m_in_dev, so, bitmap);
         SEG3D_CHECK_LAUNCH();
     }
     const unsigned nbw = (unsigned)ceil_div64(nw, kThreads);

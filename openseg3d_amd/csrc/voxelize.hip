@@ -172,7 +172,7 @@ int voxelize_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_co
 
 extern "C" {
 
-int seg3d_abi_version(void) { return 27; }
+int seg3d_abi_version(void) { return 28; }
 
 int seg3d_grid_size(const float* voxel_size, const float* range, int32_t* grid_xyz) {
     if (!voxel_size || !range || !grid_xyz) return SEG3D_EINVAL;

@@ -142,8 +142,10 @@ def rulebook_subm(h):
     return nbr
 
 
-def downsample_coords(coords, batch_size, spatial_shape):
-    """Active sites of SparseConv3d(k=3, s=2, p=1), ascending (b,z,y,x).  One host sync (reads M_out)."""
+def downsample_launch(coords, batch_size, spatial_shape, rows_dev=None):
+    """Queue the output-site build of SparseConv3d(k=3, s=2, p=1) without reading anything back: returns (buffer [cap, 4],
+    count int32 [1] on the device, shape_out).  ``rows_dev``: device count of valid rows when ``coords`` is itself such a
+    buffer (chained levels)."""
     _need_gpu(coords)
     coords = _i32c(coords)
     m, dev = coords.shape[0], coords.device
@@ -153,9 +155,28 @@ def downsample_coords(coords, batch_size, spatial_shape):
     out = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
     ws = _workspace(_lib.query("seg3d_downsample_workspace_bytes", int(batch_size), _i3(spatial_shape)), dev)
-    _lib.call("seg3d_downsample_coords", _ptr(coords), m, int(batch_size), _i3(spatial_shape), _ptr(out), cap,
+    _lib.call("seg3d_downsample_coords", _ptr(coords), m, _ptr(rows_dev), int(batch_size), _i3(spatial_shape), _ptr(out), cap,
               _ptr(count), _ptr(ws), ws.numel(), _stream())
+    return out, count, shape_out
+
+
+def downsample_coords(coords, batch_size, spatial_shape):
+    """Active sites of SparseConv3d(k=3, s=2, p=1), ascending (b,z,y,x).  One host sync (reads M_out)."""
+    out, count, shape_out = downsample_launch(coords, batch_size, spatial_shape)
     return out[: int(count.item())], shape_out
+
+
+def downsample_chain(coords, batch_size, spatial_shape, levels):
+    """Output sites of ``levels`` successive strided convs with ONE host read-back: level k + 1 is built from level k's
+    buffer and its device-side count.  Returns [(coords_k, shape_k)] for k = 1 .. levels."""
+    bufs, counts, shapes = [], [], []
+    cur, cur_shape, rows = coords, spatial_shape, None
+    for _ in range(levels):
+        out, count, shape_out = downsample_launch(cur, batch_size, cur_shape, rows)
+        bufs.append(out), counts.append(count), shapes.append(shape_out)
+        cur, cur_shape, rows = out, shape_out, count
+    ns = torch.cat(counts).tolist()
+    return [(b[: int(n)], sh) for b, n, sh in zip(bufs, ns, shapes)]
 
 
 def parity_order(coords):

@@ -183,13 +183,14 @@ class PointTransformer(nn.Module):
 
     def prepare(self, batch_dict):
         """Index plan of the whole backbone -- site levels, rulebooks, row orders, window plans of the four stages --
-        built before any feature kernel is queued.  All 4 host read-backs of a forward (3 strided levels, then the window
-        counts of all four stages at once) happen here, while only short index kernels are in flight; afterwards the feature pipeline (forward,
+        built before any feature kernel is queued.  Both host read-backs of a forward (the sizes of the three strided
+        levels, then the window counts of all four stages) happen here, while only short index kernels are in flight; afterwards the feature pipeline (forward,
         loss, backward) is enqueued without a single wait, so the host runs ahead of the GPU instead of draining the
         queue once per stage."""
         level = spconv.SiteLevel(batch_dict["voxel_coords"].int(), self.sparse_shape, batch_dict["batch_size"])
         batch_dict["site_level"] = level
         widths = (48, 96, 192, 384)
+        level.seed_chain(3)  # sites of the three strided levels: chained on the device, one read-back
         launched = []
         for k in range(4):
             level.subm()

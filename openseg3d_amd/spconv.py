@@ -43,6 +43,7 @@ class SiteLevel:
         self._subm = None
         self._down = None
         self._parity = None
+        self._coarse = None  # [(coords, shape)] of the following strided levels when seeded by seed_chain()
         self._offsets = False
         self.window_plans = {}  # SparseWindowPartitionLayer -> WindowPlan of this level (built once per forward)
 
@@ -81,12 +82,25 @@ class SiteLevel:
             self._parity = ops.parity_order(self.coords)  # stable 3-bit device radix sort (seg3d_parity_order)
         return self._parity
 
+    def seed_chain(self, levels):
+        """Build the site lists of the next ``levels`` strided levels with one host read-back (ops.downsample_chain) and
+        hand them to the down() calls that follow."""
+        if self._down is None and self._coarse is None:
+            chain = ops.downsample_chain(self.coords, self.batch_size, self.shape, levels)
+            self._coarse = chain
+
     def down(self):
         """(coarse SiteLevel, nbr_fwd [27, M_coarse], nbr_inv [27, M]) of SparseConv3d(k=3, s=2, p=1)."""
         if self._down is None:
-            co, shape_out = ops.downsample_coords(self.coords, self.batch_size, self.shape)
+            if self._coarse:
+                (co, shape_out), rest = self._coarse[0], self._coarse[1:]
+            else:
+                (co, shape_out), rest = ops.downsample_coords(self.coords, self.batch_size, self.shape), None
             fwd, inv = ops.rulebook_strided(self.hash, co)
-            self._down = (SiteLevel(co, shape_out, self.batch_size), fwd, inv)
+            coarse = SiteLevel(co, shape_out, self.batch_size)
+            coarse._coarse = rest or None
+            self._down = (coarse, fwd, inv)
+            self._coarse = None
         return self._down
 
 

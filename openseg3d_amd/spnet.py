@@ -162,6 +162,7 @@ class SparseUnet(nn.Module):
         segformer.PointTransformer.prepare)."""
         level = spconv.SiteLevel(batch_dict["voxel_coords"].int(), self.sparse_shape, batch_dict["batch_size"])
         batch_dict["site_level"] = level
+        level.seed_chain(3)
         for k in range(4):
             level.subm()
             if k >= 2:
