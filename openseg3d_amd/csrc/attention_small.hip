@@ -113,7 +113,7 @@ constexpr int kTile = 32;
 
 // ------------------------------------------------------------------ forward
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 5) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, int ldq, int ldk, int ldv,
                                                       const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                       const int32_t* __restrict__ win_count, const int2* __restrict__ tile_item,
