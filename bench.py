@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the sparse-voxel segmentation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--mode fwd|fwdbwd] [--scenes S]
+    python bench.py --gpus N --steps K --warmup W [--mode fwd|fwdbwd] [--workload ...] [--scenes S]
 
 One "step" = one pass of the hot path over one batch of synthetic input per GPU: GPU voxelisation of
 a resident Waymo-shaped scene (~180 k float32 points, 0.1 m voxels, grid 1440x1440x64, i.e.
@@ -11,9 +11,14 @@ over RCCL when N > 1).  The forward-only eval rate of the same scenes is timed i
 reported as `fwd_only` (mode fwd makes it the headline instead).  Scenes shard data-parallel: every rank processes its own scenes,
 `value` = points processed by all ranks / max-over-ranks wall time ("scaling": "weak").
 
+N > 1: either an outer launcher provides RANK / WORLD_SIZE (python -m torch.distributed.run ... bench.py --gpus N), or
+`python bench.py --gpus N` starts its own N ranks (tools/dist_train.sh:7-13 does the same for the reference) -- the
+parent spawns fresh children before it ever touches a GPU and relays rank 0's line.
+
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     -- the dominant kernel (sparse-conv gather-GEMM): algorithmic bytes / live HIP-event time
-  cpu_baseline -- the CPU oracle (port of the reference algorithm) timed on the host cores, N=1 only.
+  cpu_baseline -- the CPU oracle (port of the reference algorithm) timed on the host cores, N=1 only
+  parity       -- GPU path vs that oracle on the same sample: logits, voxel ids, rulebooks.
 """
 import argparse
 import json
@@ -27,11 +32,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
+MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md:43
+PMC_TRAFFIC_FILES = ("r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json")  # newest first
 ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
-# single-rank rehearsal of the multi-GPU path (RCCL process group, DDP wrapper, barriers) on a one-GPU box:
-# python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 with SEG3D_BENCH_DIST=1
-DIST_REHEARSAL = os.environ.get("SEG3D_BENCH_DIST", "0") == "1" and "RANK" in os.environ
+
+WORKLOADS = {
+    "one_sweep": "waymo_one_sweep (BASELINE configs[1])",
+    "cylinder": "waymo_one_sweep_cylinder (BASELINE configs[2] geometry)",
+    "multi_sweeps": "waymo_multi_sweeps + image features (BASELINE configs[3], 3 sweeps)",
+    "dense2m": "synthetic dense scene, 2 M points @0.02 m voxels in a 28.8 m x 28.8 m x 1.28 m block "
+               "(BASELINE configs[4] / SURVEY 8d Config 5)",
+}
 
 
 def parse():
@@ -40,39 +52,23 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["fwd", "fwdbwd"], default="fwdbwd")
-    ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
+    ap.add_argument("--scenes", type=int, default=0, help="distinct resident scenes per rank (0 = 4, dense2m: 2)")
     ap.add_argument("--batch", type=int, default=1, help="scenes per step per GPU")
-    ap.add_argument("--workload", choices=["one_sweep", "cylinder", "multi_sweeps"], default="one_sweep",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="one_sweep",
                     help="one_sweep = BASELINE configs[1] (the headline); cylinder = configs[2] geometry "
                          "(waymo_one_sweep_cylinder.yaml, use --batch 4); multi_sweeps = configs[3] "
-                         "(waymo_multi_sweeps.yaml + image features, 3 sweeps, use --batch 2)")
+                         "(waymo_multi_sweeps.yaml + image features, 3 sweeps, use --batch 2); dense2m = configs[4]")
     ap.add_argument("--segmentor", choices=["segformer", "spnet"], default="segformer",
                     help="MODEL.SEGMENTOR (builder.py:8-23); segformer is the headline, spnet = SparseUnet + OCR")
     ap.add_argument("--criterion", choices=["default", "ce"], default="default",
                     help="default = MODEL.LOSSES of the reference config (ohem_ce + lovasz on the point, voxel and "
                          "auxiliary heads, tools/train.py:71-110); ce = plain cross-entropy on the three heads")
+    ap.add_argument("--sync-bn", action="store_true", help="tools/train.py --sync_bn: SyncBatchNorm over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU-baseline sample (0 = whole scene)")
+    ap.add_argument("--cpu-points", type=int, default=-1,
+                    help="points of the CPU-baseline / parity sample (0 = whole scene; default: whole scene, "
+                         "150000 for dense2m so that the default run stays within minutes)")
     return ap.parse_args()
-
-
-def setup_dist(args):
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or DIST_REHEARSAL:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL over xGMI
-    torch.cuda.set_device(local)
-    return rank, world, local
-
-
-def barrier(world):
-    if world > 1 or DIST_REHEARSAL:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
 
 
 def conv_roofline(model, batch, dev):
@@ -86,7 +82,7 @@ def conv_roofline(model, batch, dev):
         e0.record()
         y = orig(x, nbr, w_packed, bias, cin, cout, order)
         e1.record()
-        records.append((nbr, cin, cout, e0, e1))
+        records.append((nbr, cin, cout, e0, e1, x.shape[0]))
         return y
 
     orig_act = ops.conv_act  # inference form of the conv blocks (BatchNorm folded, ReLU / residual in the epilogue)
@@ -96,16 +92,16 @@ def conv_roofline(model, batch, dev):
         e0.record()
         y = orig_act(x, nbr, packed, bias, cin, cout, order, addend, relu)
         e1.record()
-        records.append((nbr, cin, cout, e0, e1))
+        records.append((nbr, cin, cout, e0, e1, x.shape[0]))
         return y
 
     attn_records = []
     orig_attn = ops.window_attention_packed
 
-    def timed_attn(qk, v, tau, tau_min, heads, wi):  # noqa: E306
+    def timed_attn(qk, v, tau, tau_min, heads, wi, *a, **kw):  # noqa: E306
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        o = orig_attn(qk, v, tau, tau_min, heads, wi)
+        o = orig_attn(qk, v, tau, tau_min, heads, wi, *a, **kw)
         e1.record()
         attn_records.append((wi, v.shape[1], e0, e1))
         return o
@@ -123,29 +119,36 @@ def conv_roofline(model, batch, dev):
         ops._conv_apply = orig
         ops.conv_act = orig_act
         ops.window_attention_packed = orig_attn
-    # window attention (prepare + core kernels of one layer): algorithmic FLOPs 4*C*sum_w n_w^2
+    # window attention (all kernels of one layer's attention core): algorithmic FLOPs 4*C*sum_w n_w^2
     sq_cache, a_flop, a_ms = {}, 0.0, 0.0
+    by_width = {}
     for wi, c, e0, e1 in attn_records:
         if id(wi) not in sq_cache:
             cnt = wi.win_count[: wi.n_windows].double()
             sq_cache[id(wi)] = float((cnt * cnt).sum().item())
-        a_flop += 4.0 * c * sq_cache[id(wi)] / passes
-        a_ms += e0.elapsed_time(e1) / passes
+        fl, ms = 4.0 * c * sq_cache[id(wi)] / passes, e0.elapsed_time(e1) / passes
+        a_flop += fl
+        a_ms += ms
+        w = by_width.setdefault(c, [0.0, 0.0, 0])
+        w[0] += fl
+        w[1] += ms
+        w[2] += 1
     attn_tf = a_flop / a_ms / 1e9 if a_ms > 0 else 0.0
     global ATTENTION_REPORT
     ATTENTION_REPORT = {
-        "bound": "mfma", "kernel": "window attention of one forward, 18 encoder layers: attn_prepare_fwd + attn_core_fwd "
-                                   "(dh 24/48, split-bf16 MFMA) and attn_small_fwd (dh 6/12, exact-fp32 vector ALU)",
-        "achieved": round(attn_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(attn_tf / 2500.0, 5),
-        "note": "algorithmic 4*C*sum(n_w^2) FLOPs per layer / HIP-event time; the MFMA kernels execute 3 bf16 MFMAs "
-                "per product (split-bf16) on 32x32-token tiles, so executed MFMA FLOPs are >= 3x the algorithmic; "
-                "the two narrow-head stages do not use the matrix cores at all",
-        "layers": len(attn_records) // passes, "gflop_per_forward": round(a_flop / 1e9, 2), "ms_per_forward": round(a_ms, 3)}
+        "bound": "mfma", "kernel": "window attention core of one forward (18 encoder layers; in-projection / out-projection "
+                                   "GEMMs not included)",
+        "achieved": round(attn_tf, 2), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(attn_tf / MFMA_BF16_TFLOPS, 5),
+        "note": "algorithmic 4*C*sum(n_w^2) FLOPs per layer / HIP-event time; executed MFMA FLOPs are higher (split-bf16 "
+                "products, padding of heads and of windows to tiles)",
+        "layers": len(attn_records) // passes, "gflop_per_forward": round(a_flop / 1e9, 2), "ms_per_forward": round(a_ms, 3),
+        "by_width": {str(c): {"layers": w[2] // passes, "us_per_layer": round(w[1] * 1e3 / max(w[2] // passes, 1), 1),
+                              "TFLOPs": round(w[0] / w[1] / 1e9, 1) if w[1] > 0 else 0.0} for c, w in sorted(by_width.items())}}
     pairs_cache, tot_bytes, tot_ms = {}, 0.0, 0.0
     per_layer = []
     n_layers = len(records) // passes
     for li in range(n_layers):
-        nbr, cin, cout = records[li][:3]
+        nbr, cin, cout, _, _, m_in = records[li]
         key = nbr.data_ptr()
         if key not in pairs_cache:
             pairs_cache[key] = int((nbr >= 0).sum().item())
@@ -154,58 +157,115 @@ def conv_roofline(model, batch, dev):
         ms = sum(records[li + k * n_layers][3].elapsed_time(records[li + k * n_layers][4]) for k in range(passes)) / passes
         tot_bytes += algo
         tot_ms += ms
-        per_layer.append({"rows": int(nbr.shape[1]), "pairs": p, "cin": cin, "cout": cout, "us": round(ms * 1e3, 1),
-                          "GBs": round(algo / ms / 1e6, 1)})
+        m_out = int(nbr.shape[1])
+        # each layer against ITS bound: narrow layers move bytes (footprint = every input / output row once + W + table),
+        # wide layers multiply (useful FLOPs against the split-bf16 ceiling = bf16 MFMA peak / 3 products)
+        if max(cin, cout) <= 96:
+            foot = (m_in * cin + m_out * cout) * 4 + 27 * cin * cout * 4 + 27 * m_out * 4
+            lay = {"bound": "hbm", "frac": round(foot / ms / 1e6 / HBM_PEAK_GBS, 3)}
+        else:
+            lay = {"bound": "mfma_bf16x3", "frac": round(2.0 * p * cin * cout / ms / 1e9 / (MFMA_BF16_TFLOPS / 3.0), 3)}
+        per_layer.append({"rows": m_out, "pairs": p, "cin": cin, "cout": cout, "us": round(ms * 1e3, 1),
+                          "GBs": round(algo / ms / 1e6, 1), **lay})
     n = max(n_layers, 1)
     achieved = tot_bytes / tot_ms / 1e6 if tot_ms > 0 else 0.0
-    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE doubled per the gfx950 correction +
-    # WRITE_SIZE, two separate rocprofv3 --pmc runs of this same workload); only quoted when the profiled
-    # workload is the one just run (same algorithmic bytes), otherwise null.
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
-    if os.path.exists(pmc):
+    # HBM traffic per launch QUOTED from the committed PMC passes of this workload (FETCH_SIZE doubled per the gfx950
+    # correction + WRITE_SIZE, two separate rocprofv3 --pmc runs; counters cannot be read inside this process); only
+    # quoted when the profiled workload is the one just run (same algorithmic bytes), otherwise null.
+    traffic, traffic_src = None, None
+    for name in PMC_TRAFFIC_FILES:
+        pmc = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pmc):
+            continue
         with open(pmc) as f:
             p = json.load(f)
         if abs(p.get("algorithmic_bytes_per_launch", 0) - tot_bytes / n) <= 0.01 * tot_bytes / n:
-            traffic = p["traffic_bytes_per_launch"]
+            traffic, traffic_src = p["traffic_bytes_per_launch"], f"quoted from profiles/{name} (rocprofv3 --pmc, same workload)"
+            break
     return {"bound": "hbm", "kernel": f"spconv_split_kernel (all {n_layers} sparse-conv launches of one forward, mean of {passes} forwards)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches": n_layers,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "launches": n_layers,
             "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
 
 
-def cpu_baseline(scene_np, cfg, ds, model, n_points):
-    """The oracle (CPU restatement of the reference algorithm) on the host cores: same scene (or its first
-    n_points rows), same weights, eval forward."""
+def cpu_baseline(pts, n_cur, image, cfg, ds, model):
+    """The oracle (CPU restatement of the reference algorithm) on the host cores: the sample's points, same weights,
+    eval forward.  pts: rows of one scene (all sweeps), n_cur: its current-sweep rows, image: [n_cur, 28] or None.
+    Returns (report, oracle result dict, oracle voxel coords, oracle point->voxel ids)."""
     from oracle import index_ops, model as omodel
     # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe a larger affinity mask
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: oracle forward on {cores} host threads ...", file=sys.stderr, flush=True)
-    pts = scene_np if not n_points else scene_np[:n_points]
+    print(f"[bench] cpu_baseline: oracle forward of {pts.shape[0]} points on {cores} host threads ...", file=sys.stderr, flush=True)
     t0 = time.time()
     coords, ids = index_ops.voxelize(pts, ds.voxel_size, ds.point_cloud_range)
     batch = {"points": torch.from_numpy(np.pad(pts, ((0, 0), (1, 0)))).float(),
              "voxel_coords": torch.from_numpy(np.pad(coords, ((0, 0), (1, 0)))).float(),
-             "point_voxel_ids": torch.from_numpy(ids).long(), "batch_size": 1}
+             "point_voxel_ids": torch.from_numpy(ids).long(), "batch_size": 1,
+             "point_id_offset": torch.tensor([float(n_cur)])}
+    if image is not None:
+        batch["point_image_features"] = image.detach().cpu()
     ocfg = {"grid_size": index_ops.grid_size_of(ds.voxel_size, ds.point_cloud_range),
             "batching_info": [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO],
-            "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS}
+            "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS,
+            "use_multi_sweeps": bool(ds.use_multi_sweeps), "use_image_feature": bool(ds.use_image_feature)}
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     with torch.no_grad():
-        (omodel.spnet_forward if cfg.MODEL.SEGMENTOR == "spnet" else omodel.segformer_forward)(batch, sd, ocfg)
+        res = (omodel.spnet_forward if cfg.MODEL.SEGMENTOR == "spnet" else omodel.segformer_forward)(batch, sd, ocfg)
     dt = time.time() - t0
-    return {"value": round(pts.shape[0] / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": f"1 forward (voxelize + {cfg.MODEL.SEGMENTOR} eval) of {pts.shape[0]} points of scene seed 0, "
-                      f"{coords.shape[0]} voxels, {dt:.1f} s, torch.set_num_threads({cores})"}
+    report = {"value": round(n_cur / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
+              "sample": f"1 forward (voxelize + {cfg.MODEL.SEGMENTOR} eval) of {n_cur} points ({pts.shape[0]} rows with history "
+                        f"sweeps) of scene seed 0, {coords.shape[0]} voxels, {dt:.1f} s, torch.set_num_threads({cores})"}
+    return report, res, coords, ids
+
+
+def parity_report(pts, n_cur, image, ds, model, dev, oracle_res, oracle_coords, oracle_ids):
+    """GPU path vs the oracle on the same sample and the same weights (the `logit parity` half of the metric):
+    per-point logits within 1e-3, voxel ids and rulebooks bit-exact (BASELINE.json north_star)."""
+    from openseg3d_amd import batch as B
+    b = B.batch_from_resident(B.collate_points([pts], dev), [n_cur], ds.voxel_size, ds.point_cloud_range, image)
+    gpu_coords = b["voxel_coords"].int().cpu().numpy()
+    ids_ok = bool(np.array_equal(gpu_coords[:, 1:], oracle_coords) and (gpu_coords[:, 0] == 0).all()
+                  and np.array_equal(b["point_voxel_ids"].cpu().numpy(), oracle_ids))
+    with torch.no_grad():
+        res = model(b)
+    level = b.get("site_level")
+    books_ok = None
+    if level is not None and ids_ok:
+        books_ok = True
+        for k, ref in enumerate(oracle_res["_levels"]):
+            books_ok &= bool(np.array_equal(level.subm().cpu().numpy(), ref.subm()))
+            if k < 3:
+                coarse, fwd, inv = level.down()
+                rc, rf, ri = ref.down()
+                books_ok &= bool(np.array_equal(coarse.coords.cpu().numpy(), rc.coords)
+                                 and np.array_equal(fwd.cpu().numpy(), rf) and np.array_equal(inv.cpu().numpy(), ri))
+                level = coarse
+    out = {"n_points": int(n_cur), "voxel_ids_bit_exact": ids_ok, "rulebook_bit_exact": books_ok, "tolerance": 1e-3}
+    for key, name in (("point_out", "max_abs_logit_diff"), ("voxel_out", "max_abs_voxel_logit_diff"),
+                      ("aux_voxel_out", "max_abs_aux_logit_diff")):
+        if ids_ok:
+            out[name] = float((res[key].float().cpu() - oracle_res[key]).abs().max())
+    if ids_ok:
+        out["max_abs_logit"] = float(oracle_res["point_out"].abs().max())
+    return out
 
 
 def main():
     args = parse()
-    rank, world, local = setup_dist(args)
+    from openseg3d_amd import dist as D
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the driver's command form: start our own ranks (tools/dist_train.sh:7-13).  Nothing in this process has
+        # touched the GPU yet -- importing torch does not initialise HIP -- and nothing will: it only waits.
+        sys.exit(D.launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    share = os.environ.get("SEG3D_BENCH_SHARE_GPU", "0") == "1"  # rehearsal on a one-GPU box: all ranks on cuda:0 (gloo)
+    rank, world, local = D.init_job(backend=os.environ.get("SEG3D_BENCH_BACKEND") or "nccl", share_device=share)
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    from openseg3d_amd import batch as B, config, dist as D, scene, segformer
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from openseg3d_amd import batch as B, config, scene, segformer
     dev = torch.device("cuda", local)
     cfg = config.default_cfg()  # == configs/waymo_one_sweep.yaml for every key the model path reads
     if args.workload == "cylinder":  # configs/waymo_one_sweep_cylinder.yaml:2-4
@@ -215,22 +275,27 @@ def main():
     elif args.workload == "multi_sweeps":  # configs/waymo_multi_sweeps.yaml:1-4 + USE_IMAGE_FEATURE
         cfg.DATASET.USE_MULTI_SWEEPS = True
         cfg.DATASET.USE_IMAGE_FEATURE = True
+    elif args.workload == "dense2m":  # BASELINE configs[4]: same 1440 x 1440 x 64 grid at 0.02 m
+        cfg.DATASET.POINT_CLOUD_RANGE = list(scene.DENSE_RANGE)
+        cfg.DATASET.VOXEL_SIZE = list(scene.DENSE_VOXEL)
     cfg.MODEL.SEGMENTOR = args.segmentor
     ds = config.DatasetSpec(cfg)
     torch.manual_seed(0)
     model = segformer.build_segmentor(cfg, ds).to(dev)
 
     # resident synthetic scenes: seeds differ per rank (data-parallel shards of the scene stream)
-    seeds = [rank * args.scenes * args.batch + i for i in range(args.scenes * args.batch)]
+    n_scenes = args.scenes or (2 if args.workload == "dense2m" else 4)
+    seeds = [rank * n_scenes * args.batch + i for i in range(n_scenes * args.batch)]
     if args.workload == "multi_sweeps":
         made = [scene.make_multi_sweep_scene(s, cfg.DATASET.NUM_SWEEPS) for s in seeds]
         scenes_np, n_cur = [m[0] for m in made], [m[1] for m in made]
     else:
-        scenes_np = [scene.make_scene(s) for s in seeds]
+        make = scene.make_dense_scene if args.workload == "dense2m" else scene.make_scene
+        scenes_np = [make(s) for s in seeds]
         if args.workload == "cylinder":
             scenes_np = [scene.cart2polar_rows(s) for s in scenes_np]
         n_cur = [s.shape[0] for s in scenes_np]
-    groups = [list(range(i * args.batch, (i + 1) * args.batch)) for i in range(args.scenes)]
+    groups = [list(range(i * args.batch, (i + 1) * args.batch)) for i in range(n_scenes)]
     resident = [B.collate_points([scenes_np[j] for j in g], dev) for g in groups]
     offsets = [np.cumsum([n_cur[j] for j in g]).tolist() for g in groups]  # cumulative current-sweep rows
     images = [None] * len(groups)
@@ -240,14 +305,14 @@ def main():
     pts_per_step = [int(o[-1]) for o in offsets]  # points that receive logits
 
     train = args.mode == "fwdbwd"
+    net = model
+    if train and distributed:  # tools/train.py:246-247, 276-279
+        net = D.wrap_data_parallel(model, dev, sync_bn=args.sync_bn)
+        model = net.module
     # configs/waymo_one_sweep.yaml: SGD, momentum 0.9, weight decay 1e-4; torch's fused multi-tensor implementation
     # (same arithmetic, 3 launches instead of 24) unless SEG3D_BENCH_FOREACH_SGD=1
     opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4,
                           fused=os.environ.get("SEG3D_BENCH_FOREACH_SGD", "0") != "1")
-    net = model
-    if train and (world > 1 or DIST_REHEARSAL):
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
-                                                        broadcast_buffers=False, gradient_as_bucket_view=True)
     labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
     from openseg3d_amd import losses as _losses, ops as _ops
     if args.criterion == "ce":
@@ -283,19 +348,19 @@ def main():
     def timed(step_fn):
         for i in range(args.warmup):
             step_fn(i)
-        barrier(world)
+        D.job_barrier(dev)
         t0 = time.perf_counter()
         for i in range(args.steps):
             step_fn(args.warmup + i)
-        barrier(world)
+        D.job_barrier(dev)
         sec = time.perf_counter() - t0
         pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
         return D.aggregate_throughput(sec, pts, dev)
 
     if train:
-        model.train()
+        net.train()
         dt, n_pts = timed(train_step)
-    model.eval()
+    net.eval()
     dt_f, n_pts_f = timed(fwd_step)  # forward-only eval (BASELINE configs[1] as literally worded)
     if not train:
         dt, n_pts = dt_f, n_pts_f
@@ -305,32 +370,44 @@ def main():
         model.eval()
         b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0])
         roof, per_layer = conv_roofline(model, b0, dev)
+        if train:
+            step_desc = "fwd + criterion (" + "+".join(cfg.MODEL.LOSSES) + " on 3 heads) + bwd + SGD step"
+        else:
+            step_desc = "forward-only eval"
         out = {
             "metric": "points/sec fwd+bwd, Waymo 1-sweep ~180k pts @0.1m voxel; logit parity",
             "value": round(n_pts / dt, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"one_sweep": "waymo_one_sweep (BASELINE configs[1])",
-                                    "cylinder": "waymo_one_sweep_cylinder (BASELINE configs[2] geometry)",
-                                    "multi_sweeps": "waymo_multi_sweeps + image features (BASELINE configs[3], 3 sweeps)"
-                                    }[args.workload] + ": synthetic 64-beam scene, "
-                                   f"{pts_per_step[0]} pts/step/GPU, voxel {ds.voxel_size}, grid {ds.grid_size.tolist()}, "
-                                   f"{'forward-only eval' if not train else 'fwd + criterion (' + '+'.join(cfg.MODEL.LOSSES) + ' on 3 heads) + bwd + SGD step'}",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 storage/accumulate, bf16x3 products" if _ops.CONV_PRECISION == "bf16x3" else "f32",
+            "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload] + ": synthetic scene, "
+                                   f"{pts_per_step[0]} pts/step/GPU, voxel {ds.voxel_size}, grid {ds.grid_size.tolist()}, {step_desc}",
                        "mode": args.mode, "segmentor": args.segmentor, "scenes_per_step_per_gpu": args.batch,
-                       "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}"},
+                       "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}",
+                       "collective": (f"{dist.get_backend()} world {dist.get_world_size()}" + (", SyncBatchNorm" if args.sync_bn else ""))
+                       if distributed else None},
             "fwd_only": {"value": round(n_pts_f / dt_f, 1), "unit": "points/s",
                          "ms_per_step": round(dt_f / args.steps * 1e3, 3)},
             "roofline": roof,
+            "conv_layers": [{k: l[k] for k in ("rows", "cin", "cout", "us", "bound", "frac")} for l in per_layer],
             "attention_roofline": ATTENTION_REPORT if args.segmentor == "segformer" else None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scenes_np[0], cfg, ds, model, args.cpu_points)
+            n_cpu = args.cpu_points if args.cpu_points >= 0 else (150000 if args.workload == "dense2m" else 0)
+            sample, s_cur, s_img = scenes_np[0], n_cur[0], None
+            if args.workload == "multi_sweeps":  # whole scene: the history sweeps and the image rows belong together
+                s_img = images[0][: n_cur[0]]
+            elif n_cpu:
+                sample = sample[:n_cpu]
+                s_cur = sample.shape[0]
+            out["cpu_baseline"], o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
+            out["parity"] = parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
             json.dump(per_layer, f, indent=1)
         print(json.dumps(out), flush=True)
-    if world > 1 or DIST_REHEARSAL:
-        import torch.distributed as dist
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -41,6 +41,14 @@ extern "C" {
 /* ABI version; bumped whenever a signature below changes. */
 int seg3d_abi_version(void);
 
+/* Text of the HIP runtime error behind the calling thread's most recent SEG3D_ELAUNCH
+ * ("<hipGetErrorString> (<hipGetErrorName>) at <file>:<line>"), "" if none yet.  The reference
+ * surfaces argument failures as Python exceptions through TORCH_CHECK
+ * (seg3d/ops/ingroup_inds/src/ingroup_inds.cpp:6-12) and checks nothing after its kernel launches
+ * (ingroup_inds_cuda.cu:35-49); a C ABI that returns codes needs an accessor for the runtime's text.
+ * The pointer stays valid for the life of the thread. */
+const char* seg3d_last_error(void);
+
 /* ------------------------------------------------------------------------------------------
  * a2  VoxelGenerator.__init__  -- seg3d/core/voxel/voxel_generator.py:11-22
  * grid = round((hi - lo) / voxel_size) evaluated in float32 (host helper, no GPU work).
@@ -151,6 +159,11 @@ int seg3d_spconv_fwd_act(const float* x, const int32_t* nbr, int64_t m_out, int6
                          int32_t pack_flags, const float* bias /*or NULL*/, const float* addend /*or NULL*/,
                          int32_t relu, int32_t cin, int32_t cout, float* y, const int32_t* row_order /*or NULL*/,
                          void* stream);
+/* Test hook: force the column-block width (x16 columns) of the split-bf16 gather-GEMM so that every kernel
+ * instantiation can be pinned against the oracle at any row count (0 = automatic choice; 1, 2, 3, 4, 6, 12).
+ * Same effect as the SEG3D_CONV_NBT environment variable, which is read once when the library loads.
+ * The reference has no counterpart (spconv chooses its own tiles). */
+int seg3d_debug_set_conv_nbt(int32_t nbt);
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout);
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out,
                        int64_t m_in, int32_t cin, int32_t cout, int32_t flags /* bit2: split-bf16 */,
@@ -310,6 +323,16 @@ int seg3d_affine_act(const float* x, const float* res, const float* scale, const
 int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                         const float* gamma, int32_t relu, int64_t m, int32_t c, float* dx, float* dres,
                         float* sums, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.nn.SyncBatchNorm (tools/train.py:246-247, --sync_bn): the two halves of seg3d_batchnorm_bwd as separate
+ * entries.  _reduce writes the rank-local sums = {sum g, sum g*xhat} (= dbeta, dgamma of this rank, which is what
+ * torch's SyncBatchNorm hands DDP); the caller all-reduces a copy over the ranks and passes it to _apply together
+ * with inv_count = device float[1] holding 1 / (rows of all ranks); mean / rstd are the synchronised statistics. */
+int seg3d_batchnorm_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean,
+                               const float* rstd, int32_t relu, int64_t m, int32_t c, float* sums,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int seg3d_batchnorm_bwd_apply(const float* dy, const float* y, const float* x, const float* mean,
+                              const float* rstd, const float* gamma, const float* sums, const float* inv_count,
+                              int32_t relu, int64_t m, int32_t c, float* dx, float* dres, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a7, a25, a26  torch_scatter.scatter(src, index, dim=0, reduce='mean'|'max') at

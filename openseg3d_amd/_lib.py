@@ -13,13 +13,14 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); must match include/seg3d_hip.h (tests/test_boundary.py cross-checks the names)
 SIGNATURES = {
     "seg3d_abi_version": (ctypes.c_int, []),
+    "seg3d_last_error": (ctypes.c_char_p, []),
     "seg3d_grid_size": (ctypes.c_int, [_p, _p, _p]),
     "seg3d_voxelize_workspace_bytes": (_sz, [_i64]),
     "seg3d_voxelize_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "seg3d_spconv_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_spconv_fwd": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_spconv_fwd_act": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    "seg3d_debug_set_conv_nbt": (ctypes.c_int, [_i32]),
     "seg3d_spconv_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "seg3d_spconv_wgrad": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "seg3d_linear_packed_bytes_f32": (ctypes.c_size_t, [_i32, _i32]),
@@ -65,6 +67,8 @@ SIGNATURES = {
     "seg3d_batchnorm_stats": (ctypes.c_int, [_p, _i64, _i32, _f, _p, _p, _f, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_affine_act": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
     "seg3d_batchnorm_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p, ctypes.c_size_t, _p]),
+    "seg3d_batchnorm_bwd_reduce": (ctypes.c_int, [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, ctypes.c_size_t, _p]),
+    "seg3d_batchnorm_bwd_apply": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p]),
     "seg3d_segment_reduce_fwd": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
     "seg3d_segment_reduce_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p, _i64, _i32, _p, _p]),
     "seg3d_voxel_majority_labels": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
@@ -126,9 +130,14 @@ def load():
 
 def call(name, *args):
     """Invoke an int-returning entry point; negative return codes raise Seg3dError."""
-    rc = getattr(load(), name)(*args)
+    lib = load()
+    rc = getattr(lib, name)(*args)
     if rc != OK:
-        raise Seg3dError(f"{name} failed: {_ERR.get(rc, rc)}")
+        detail = ""
+        if rc == ELAUNCH:  # the runtime's own words (hipGetErrorString) for the failure behind SEG3D_ELAUNCH
+            text = lib.seg3d_last_error()
+            detail = f": {text.decode(errors='replace')}" if text else ""
+        raise Seg3dError(f"{name} failed: {_ERR.get(rc, rc)}{detail}")
 
 
 def query(name, *args):

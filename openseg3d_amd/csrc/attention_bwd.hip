@@ -979,7 +979,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
                           float* dk, float* dv, int32_t lddq, int32_t lddk, int32_t lddv, float* dtau, void* workspace,
                           size_t workspace_bytes, void* stream) {
     if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) {
-        if (dtau && hipMemsetAsync(dtau, 0, sizeof(float), as_stream(stream)) != hipSuccess) return SEG3D_ELAUNCH;
+        if (dtau) SEG3D_CHECK_HIP(hipMemsetAsync(dtau, 0, sizeof(float), as_stream(stream)));
         return SEG3D_OK;
     }
     if (!q || !k || !v || !out || !dout || !lse || !tok || !win_start || !win_count || !win_tile0 || !tile_item ||

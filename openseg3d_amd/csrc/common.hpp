@@ -7,9 +7,26 @@
 
 #define SEG3D_WAVE 64
 
-#define SEG3D_CHECK_LAUNCH()                         \
-    do {                                             \
-        if (hipGetLastError() != hipSuccess) return SEG3D_ELAUNCH; \
+// The failing hipError_t is kept (per thread) for seg3d_last_error(): a bare SEG3D_ELAUNCH says nothing about why.
+void seg3d_note_hip_error(int code, const char* file, int line);
+
+#define SEG3D_CHECK_LAUNCH()                                          \
+    do {                                                              \
+        const hipError_t seg3d_e_ = hipGetLastError();                \
+        if (seg3d_e_ != hipSuccess) {                                 \
+            seg3d_note_hip_error((int)seg3d_e_, __FILE__, __LINE__);  \
+            return SEG3D_ELAUNCH;                                     \
+        }                                                             \
+    } while (0)
+
+// same for runtime calls that return their hipError_t (memsets, rocPRIM launches)
+#define SEG3D_CHECK_HIP(expr)                                         \
+    do {                                                              \
+        const hipError_t seg3d_e_ = (expr);                           \
+        if (seg3d_e_ != hipSuccess) {                                 \
+            seg3d_note_hip_error((int)seg3d_e_, __FILE__, __LINE__);  \
+            return SEG3D_ELAUNCH;                                     \
+        }                                                             \
     } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

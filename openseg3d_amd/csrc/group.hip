@@ -79,7 +79,7 @@ int group_index_launch(const int32_t* gid, int64_t n, int64_t ng, int32_t* rank,
     GrpWs w = carve(workspace, n, ng);
     // count and cursor are adjacent pieces: one memset covers both
     const size_t zero_bytes = (size_t)(reinterpret_cast<char*>(w.offs) - reinterpret_cast<char*>(w.count));
-    if (hipMemsetAsync(w.count, 0, zero_bytes, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(w.count, 0, zero_bytes, st));
     const unsigned nb = (unsigned)ceil_div64(n > 0 ? n : 1, kThreads);
     if (n > 0) {
         hipLaunchKernelGGL(grp_count, dim3(nb), dim3(kThreads), 0, st, gid, n, ng, w.count);

@@ -396,7 +396,7 @@ int sorted_cells(const float* xyz, int64_t n, const int32_t* offset, int32_t bat
     rocprim::double_buffer<SortKey> kb(sb.k0, sb.k1);
     rocprim::double_buffer<uint32_t> vb(sb.v0, sb.v1);
     size_t bytes = sb.tmp_bytes;
-    if (rocprim::radix_sort_pairs(sb.tmp, bytes, kb, vb, (size_t)n, 0u, kKeyBits, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(rocprim::radix_sort_pairs(sb.tmp, bytes, kb, vb, (size_t)n, 0u, kKeyBits, st));
     *skeys = kb.current();
     *srows = vb.current();
     return SEG3D_OK;
@@ -421,7 +421,7 @@ extern "C" int seg3d_knn_level_build(const float* xyz, int64_t n, const int32_t*
     if (capacity < 2 * n || capacity <= 0 || (capacity & (capacity - 1)) || capacity > (1ll << 31)) return SEG3D_EINVAL;
     if (!table_keys || !table_vals) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(table_keys, 0xFF, (size_t)capacity * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(table_keys, 0xFF, (size_t)capacity * 8, st));
     if (n == 0) return SEG3D_OK;
     if (!xyz || !offset || !sorted_xyz || !src_index || !cell_end) return SEG3D_EINVAL;
     SortBuffers sb;
@@ -470,7 +470,7 @@ extern "C" int seg3d_parity_order(const int32_t* coords, int64_t m, int32_t* ord
     rocprim::double_buffer<SortKey> kb(sb.k0, sb.k1);
     rocprim::double_buffer<uint32_t> vb(sb.v0, sb.v1);
     size_t bytes = sb.tmp_bytes;
-    if (rocprim::radix_sort_pairs(sb.tmp, bytes, kb, vb, (size_t)m, 0u, 3u, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(rocprim::radix_sort_pairs(sb.tmp, bytes, kb, vb, (size_t)m, 0u, 3u, st));
     hipLaunchKernelGGL(knn_copy_order, dim3((unsigned)ceil_div64(m, kThreads)), dim3(kThreads), 0, st, vb.current(), (int)m, order);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;

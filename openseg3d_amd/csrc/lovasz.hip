@@ -277,8 +277,7 @@ extern "C" int seg3d_lovasz_softmax_fwd(const float* logits, const int64_t* labe
         rocprim::double_buffer<Key> kb(k0, k1);
         rocprim::double_buffer<uint32_t> vb(v0, v1);
         size_t bytes = pl.sort_bytes;
-        if (rocprim::radix_sort_pairs_desc(sort_tmp, bytes, kb, vb, t, 0u, 32u + class_bits(c), st) != hipSuccess)
-            return SEG3D_ELAUNCH;
+        SEG3D_CHECK_HIP(rocprim::radix_sort_pairs_desc(sort_tmp, bytes, kb, vb, t, 0u, 32u + class_bits(c), st));
         const dim3 grid((unsigned)pl.nchunks, (unsigned)c);
         hipLaunchKernelGGL(lovasz_count, grid, dim3(kThreads), 0, st, vb.current(), ni, pl.nchunks, chunk_cnt);
         SEG3D_CHECK_LAUNCH();

@@ -316,9 +316,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ x, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ sums /*[2][c]*/, int relu,
-                                                                float inv_m, int64_t total_quads, int quads,
+                                                                float inv_m, const float* __restrict__ inv_m_dev,
+                                                                int64_t total_quads, int quads,
                                                                 float* __restrict__ dx, float* __restrict__ dres) {
     const int c = quads * 4;
+    if (inv_m_dev) inv_m = inv_m_dev[0];  // SyncBatchNorm: 1 / (rows of all ranks), known on the device only
     for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < total_quads; t += (int64_t)gridDim.x * kThreads) {
         const int q = (int)(t % quads);
         float4 g = reinterpret_cast<const float4*>(dy)[t];
@@ -510,7 +512,37 @@ int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const f
     SEG3D_CHECK_LAUNCH();
     const int64_t tq = m * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(tq, kThreads * 4)), dim3(kThreads), 0, st, dy, y, x, mean, rstd,
-                       gamma, sums, relu, 1.0f / (float)m, tq, c / 4, dx, dres);
+                       gamma, sums, relu, 1.0f / (float)m, nullptr, tq, c / 4, dx, dres);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+// The two halves of seg3d_batchnorm_bwd as separate entries, for torch.nn.SyncBatchNorm (tools/train.py:246-247): the
+// caller all-reduces `sums` over the ranks between them and hands the apply pass 1 / (total rows) as a device scalar.
+int seg3d_batchnorm_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                               int32_t relu, int64_t m, int32_t c, float* sums, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (m <= 0 || bad_c(c) || !sums) return SEG3D_EINVAL;
+    if (!workspace || workspace_bytes < seg3d_batchnorm_workspace_bytes(m, c)) return SEG3D_EWORKSPACE;
+    if (!dy || !x || !mean || !rstd || (relu && !y)) return SEG3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const unsigned nb = col_blocks(m, c);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(nb), dim3(kThreads), kColSmem, st, x, dy, y, mean, rstd, relu, m, c, part);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(col_sums_finish, dim3((unsigned)((2 * c + 31) / 32)), dim3(1024), 0, st, part, (int)nb, c, sums);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+int seg3d_batchnorm_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                              const float* gamma, const float* sums, const float* inv_count, int32_t relu, int64_t m,
+                              int32_t c, float* dx, float* dres, void* stream) {
+    if (m <= 0 || bad_c(c) || !sums || !inv_count) return SEG3D_EINVAL;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || (relu && !y)) return SEG3D_EINVAL;
+    const int64_t tq = m * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(tq, kThreads * 4)), dim3(kThreads), 0, as_stream(stream), dy, y, x,
+                       mean, rstd, gamma, sums, relu, 0.0f, inv_count, tq, c / 4, dx, dres);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

@@ -137,7 +137,7 @@ int seg3d_coord_hash_build(const int32_t* coords, int64_t m, const int32_t* shap
     if (table_bytes < cap * 12) return SEG3D_EWORKSPACE;
     hipStream_t st = as_stream(stream);
     HashView h = hash_view(table, cap);
-    if (hipMemsetAsync(h.keys, 0xFF, cap * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, cap * 8, st));
     if (m == 0) return SEG3D_OK;
     hipLaunchKernelGGL(hash_fill, dim3((unsigned)ceil_div64(m, kThreads)), dim3(kThreads), 0, st, coords, m,
                        shape_of(shape_zyx), h);
@@ -182,7 +182,7 @@ int seg3d_downsample_coords(const int32_t* coords_in, int64_t m_in, const int32_
     uint32_t* bitmap = c.take<uint32_t>((size_t)nw + 1);
     uint32_t* cnt = c.take<uint32_t>((size_t)nw + 1);
     uint32_t* tmp = c.take<uint32_t>(scan_tmp_count(nw));
-    if (hipMemsetAsync(bitmap, 0, (size_t)nw * 4, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)nw * 4, st));
     if (m_in > 0) {
         hipLaunchKernelGGL(down_mark, dim3((unsigned)ceil_div64(m_in, kThreads)), dim3(kThreads), 0, st, coords_in, m_in,
                            m_in_dev, so, bitmap);
@@ -206,7 +206,7 @@ int seg3d_rulebook_strided(const int32_t* coords_out, int64_t m_out, int64_t m_i
     if (table_bytes < cap * 12) return SEG3D_EWORKSPACE;
     hipStream_t st = as_stream(stream);
     if (nbr_inv && m_in > 0)
-        if (hipMemsetAsync(nbr_inv, 0xFF, (size_t)27 * m_in * 4, st) != hipSuccess) return SEG3D_ELAUNCH;
+        SEG3D_CHECK_HIP(hipMemsetAsync(nbr_inv, 0xFF, (size_t)27 * m_in * 4, st));
     if (m_out == 0) return SEG3D_OK;
     HashView h = hash_view(const_cast<void*>(table_in), cap);
     hipLaunchKernelGGL(strided_table, dim3((unsigned)ceil_div64(m_out, kThreads), 27), dim3(kThreads), 0, st, coords_out,

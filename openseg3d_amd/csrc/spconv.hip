@@ -370,7 +370,7 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
     if (m_out > 0 && (!x || !dy || !nbr)) return SEG3D_EINVAL;
     // split-bf16: partial blocks per row chunk in the workspace, summed in a fixed order (writes all of dw)
     if (m_out > 0 && (flags & 4)) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, workspace, workspace_bytes, st);
-    if (hipMemsetAsync(dw, 0, (size_t)27 * cin * cout * sizeof(float), st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)27 * cin * cout * sizeof(float), st));
     if (m_out == 0) return SEG3D_OK;
     const int ja = pick_j(cin), jb = pick_j(cout);
     switch (ja) {

@@ -16,6 +16,7 @@
 // in flight while chunk c computes (their waits sit behind the MFMAs); one barrier per chunk; the table
 // entries of the next offset are loaded one offset ahead.  Offsets with no active
 // neighbour in the whole tile are never visited; a wave whose own rows have none skips gather and MFMAs.
+#include <atomic>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -305,14 +306,21 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                 float* yr = y + orow * cout + nb0 * 16 + c16;
                 // y = act(x W^T + b (+ addend)): addend = a second gradient path, or the residual of a conv block whose
                 // BatchNorm was folded into W and b (eval); relu = that block's activation
-                const float lo = relu ? 0.0f : -INFINITY;
+                // relu as torch.relu computes it: a NaN stays a NaN (fmaxf would return the other operand and hide a
+                // diverged accumulator behind a 0); without relu the value is stored untouched
                 if (addend) {
                     const float* ar = addend + orow * cout + nb0 * 16 + c16;
 #pragma unroll
-                    for (int n = 0; n < NBT; ++n) yr[n * 16] = fmaxf(acc[rb][n][r] + ar[n * 16], lo);
+                    for (int n = 0; n < NBT; ++n) {
+                        const float v = acc[rb][n][r] + ar[n * 16];
+                        yr[n * 16] = relu ? (v < 0.0f ? 0.0f : v) : v;
+                    }
                 } else {
 #pragma unroll
-                    for (int n = 0; n < NBT; ++n) yr[n * 16] = fmaxf(acc[rb][n][r], lo);
+                    for (int n = 0; n < NBT; ++n) {
+                        const float v = acc[rb][n][r];
+                        yr[n * 16] = relu ? (v < 0.0f ? 0.0f : v) : v;
+                    }
                 }
             }
         }
@@ -349,6 +357,19 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
     return SEG3D_OK;
 }
 
+// Forced column-block width (x16) of the gather-GEMM: SEG3D_CONV_NBT read ONCE at load time, or set by
+// seg3d_debug_set_conv_nbt (parity tests pin each instantiation with it); 0 = automatic.
+static std::atomic<int> g_forced_nbt{[] {
+    const char* e = getenv("SEG3D_CONV_NBT");
+    return e ? atoi(e) : 0;
+}()};
+
+extern "C" int seg3d_debug_set_conv_nbt(int32_t nbt) {
+    if (nbt != 0 && nbt != 1 && nbt != 2 && nbt != 3 && nbt != 4 && nbt != 6 && nbt != 12) return SEG3D_EINVAL;
+    g_forced_nbt.store(nbt, std::memory_order_relaxed);
+    return SEG3D_OK;
+}
+
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
@@ -362,10 +383,7 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
     else if (nb % 4 == 0) pick = 4;
     else if (nb % 3 == 0) pick = 3;
     else if (nb % 2 == 0) pick = 2;
-    if (const char* e = getenv("SEG3D_CONV_NBT")) {
-        const int w = atoi(e);
-        if (w > 0 && nb % w == 0) pick = w;
-    }
+    if (const int w = g_forced_nbt.load(std::memory_order_relaxed); w > 0 && nb % w == 0) pick = w;
     switch (pick) {
         case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
         case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);

@@ -8,6 +8,8 @@
 // the head lane of every run of equal keys and only heads touch the table.  Pass 2 flags the
 // creating points, an exclusive scan over the flags yields the first-seen rank, pass 3 writes
 // ids and coordinates.  HBM-bound integer work: N*(12 B read + 4 B write) + M*16 B algorithmic.
+#include <cstdio>
+
 #include "common.hpp"
 
 namespace {
@@ -149,10 +151,10 @@ int voxelize_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_co
     }
     VoxWs w = carve(workspace, n);
     HashView h = hash_view(w.table, w.cap);
-    if (hipMemsetAsync(h.keys, 0xFF, w.cap * 8, st) != hipSuccess) return SEG3D_ELAUNCH;
-    if (hipMemsetAsync(h.vals, 0x7F, w.cap * 4, st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(h.keys, 0xFF, w.cap * 8, st));
+    SEG3D_CHECK_HIP(hipMemsetAsync(h.vals, 0x7F, w.cap * 4, st));
     if (n == 0) {
-        if (hipMemsetAsync(n_voxels, 0, 4, st) != hipSuccess) return SEG3D_ELAUNCH;
+        SEG3D_CHECK_HIP(hipMemsetAsync(n_voxels, 0, 4, st));
         return SEG3D_OK;
     }
     const unsigned nb = (unsigned)ceil_div64(n, kThreads);
@@ -172,7 +174,13 @@ int voxelize_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_co
 
 extern "C" {
 
-int seg3d_abi_version(void) { return 28; }
+int seg3d_abi_version(void) { return 29; }
+
+namespace {
+thread_local char g_last_error[320] = "";
+}
+
+const char* seg3d_last_error(void) { return g_last_error; }
 
 int seg3d_grid_size(const float* voxel_size, const float* range, int32_t* grid_xyz) {
     if (!voxel_size || !range || !grid_xyz) return SEG3D_EINVAL;
@@ -203,3 +211,12 @@ int seg3d_voxelize_f64(const double* points, int64_t n_points, int32_t row_strid
 }
 
 }  // extern "C"
+
+// SEG3D_CHECK_LAUNCH / SEG3D_CHECK_HIP land here: keep the runtime's own words for seg3d_last_error()
+void seg3d_note_hip_error(int code, const char* file, int line) {
+    const char* base = file;
+    for (const char* p = file; *p; ++p)
+        if (*p == '/') base = p + 1;
+    snprintf(g_last_error, sizeof(g_last_error), "%s (%s) at %s:%d", hipGetErrorString((hipError_t)code),
+             hipGetErrorName((hipError_t)code), base, line);
+}

@@ -205,7 +205,7 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
         lv.hi[j] = j < n_levels ? level_hi[j] : 0;
         lv.cap[j] = j < n_levels ? level_cap[j] : 0;
     }
-    if (hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st) != hipSuccess) return SEG3D_ELAUNCH;
+    SEG3D_CHECK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st));
     if (m == 0) return SEG3D_OK;
 
     const unsigned nbv = (unsigned)ceil_div64(m, kThreads), nbc = (unsigned)ceil_div64((int64_t)nc, kThreads);

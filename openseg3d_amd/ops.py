@@ -312,6 +312,12 @@ def pack_weight(weight, flags, use_registry=True):
     return PackedWeight(out, flags)
 
 
+def debug_set_conv_nbt(nbt):
+    """Test hook (seg3d_debug_set_conv_nbt): force the column-block width (x16) of the split-bf16 gather-GEMM;
+    0 restores the automatic choice.  Results never depend on it."""
+    _lib.call("seg3d_debug_set_conv_nbt", int(nbt))
+
+
 def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
@@ -590,6 +596,109 @@ class _BatchNormActFn(torch.autograd.Function):
         return dx, dres, sums[1], sums[0], None, None, None, None, None
 
 
+# ---- torch.nn.SyncBatchNorm (tools/train.py:246-247, --sync_bn): statistics over the rows of ALL ranks
+def _sync_bn_group(bn):
+    """Process group to synchronise over, or None: only a SyncBatchNorm in training mode inside an initialised
+    job with more than one rank synchronises (torch's own rule, nn/modules/batchnorm.py SyncBatchNorm.forward)."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not bn.training:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
+def combine_moments(mean, m2, count):
+    """Chan's parallel-variance merge.  mean, m2: [ranks, c] per-rank mean and sum of squared deviations from it;
+    count: [ranks, 1] rows per rank.  Returns (mean [c], m2 [c], total [1]) of the union, on the inputs' device."""
+    total = count.sum(dim=0)
+    g_mean = (mean * count).sum(dim=0) / total
+    g_m2 = (m2 + count * (mean - g_mean) ** 2).sum(dim=0)
+    return g_mean, g_m2, total
+
+
+def _all_gather_rows(t, group):
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":  # the CPU-side rehearsal backend has no all_gather_into_tensor on devices
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        return torch.stack(parts)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+class _SyncBatchNormActFn(torch.autograd.Function):
+    """act(x * scale + shift (+ res)) with statistics of all ranks; backward all-reduces {sum g, sum g * xhat} between
+    the reduce and apply halves (seg3d_batchnorm_bwd_reduce / _apply).  dgamma / dbeta stay rank-local, as in torch's
+    SyncBatchNorm: DDP averages them with every other parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, mean, rstd, scale, shift, inv_count, relu, group):
+        m, c = x.shape
+        y = torch.empty_like(x)
+        r = None if res is None else _f32c(res)
+        _lib.call("seg3d_affine_act", _ptr(x), _ptr(r), _ptr(scale), _ptr(shift), int(relu), m, c, _ptr(y), _stream())
+        ctx.save_for_backward(x, y, mean, rstd, gamma, inv_count)
+        ctx.relu, ctx.has_res, ctx.group = relu, res is not None, group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, y, mean, rstd, gamma, inv_count = ctx.saved_tensors
+        dy = _f32c(dy)
+        m, c = x.shape
+        sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, c)
+        ws = _workspace(ws_bytes, x.device)
+        if m > 0:
+            _lib.call("seg3d_batchnorm_bwd_reduce", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), int(ctx.relu), m, c,
+                      _ptr(sums), _ptr(ws), ws_bytes, _stream())
+        else:
+            sums.zero_()
+        total = sums.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        if m > 0:
+            _lib.call("seg3d_batchnorm_bwd_apply", _ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                      _ptr(total), _ptr(inv_count), int(ctx.relu), m, c, _ptr(dx), _ptr(dres), _stream())
+        return dx, dres, sums[1], sums[0], None, None, None, None, None, None, None
+
+
+def _sync_batch_norm_act(x, bn, relu, res, group):
+    xc = _f32c(x)
+    m, c = xc.shape
+    with torch.no_grad():
+        sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, c)
+        ws = _workspace(ws_bytes, x.device)
+        if m > 0:
+            _lib.call("seg3d_colstats", _ptr(xc), m, c, _ptr(sums), _ptr(ws), ws_bytes, _stream())
+            d = sums[0] / m  # shifted sums: mean of (x - x[0]) and the squared deviations from the local mean
+            local = torch.cat([xc[0] + d, sums[1] - sums[0] * d, torch.full((1,), float(m), device=x.device)])
+        else:  # a rank without rows still takes part in the exchange, with weight 0
+            local = torch.zeros((2 * c + 1,), dtype=torch.float32, device=x.device)
+        g = _all_gather_rows(local, group)
+        mean, m2, total = combine_moments(g[:, :c], g[:, c:2 * c], g[:, 2 * c:])
+        var = (m2 / total).clamp_(min=0.0)
+        rstd = torch.rsqrt(var + bn.eps)
+        scale = (bn.weight * rstd).contiguous()
+        shift = (bn.bias - mean * scale).contiguous()
+        if bn.track_running_stats:
+            bn._seg3d_stats_epoch = getattr(bn, "_seg3d_stats_epoch", 0) + 1
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(m2 / (total - 1).clamp_(min=1.0), alpha=mom)
+        inv_count = (1.0 / total).to(torch.float32).contiguous()
+    return _SyncBatchNormActFn.apply(xc, res, bn.weight, bn.bias, mean.contiguous(), rstd.contiguous(), scale, shift, inv_count,
+                                     bool(relu), group)
+
+
 def narrow_batch_norm(x, bn):
     """Training-mode BatchNorm1d over [rows, C] with C not a multiple of 4 (the raw 6 / 8 point channels): the rows and
     the affine parameters are zero-padded to the next multiple of 4 and run through the same statistics / affine /
@@ -638,6 +747,10 @@ def batch_norm_act(x, bn, relu=True, res=None):
     c = x.shape[1]
     fits = x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and c % 4 == 0 and c <= 1024 and bn.affine
     use_batch = bn.training or not bn.track_running_stats
+    if fits and use_batch:
+        group = _sync_bn_group(bn)
+        if group is not None:  # --sync_bn: statistics over the rows of all ranks (every rank must take this branch, so
+            return _sync_batch_norm_act(x, bn, relu, res, group)  # it comes before the small-batch fallback below)
     if not fits or (not use_batch and torch.is_grad_enabled() and x.requires_grad) or x.shape[0] < 2:
         y = bn(x)
         if res is not None:

@@ -68,7 +68,10 @@ class FusedMLP(nn.Sequential):
         i = 0
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, nn.BatchNorm1d) and not isinstance(m, NarrowBatchNorm1d):
+            # SyncBatchNorm (convert_sync_batchnorm, tools/train.py:246-247) takes the same fused pass: ops.batch_norm_act
+            # synchronises its statistics over the ranks; 6 / 8-channel inputs do not fit it and stay on torch's module
+            if isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and not isinstance(m, NarrowBatchNorm1d) \
+                    and m.num_features % 4 == 0:
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = ops.batch_norm_act(x, m, relu=relu)
                 i += 2 if relu else 1

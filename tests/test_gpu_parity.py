@@ -142,7 +142,7 @@ def test_sparse_conv_forward_and_backward(dev, golden_dir, monkeypatch, cin, cou
     from openseg3d_amd import ops, spconv
     monkeypatch.setattr(ops, "CONV_PRECISION", precision)
     coords, bs = _golden_coords(golden_dir)
-    if cin >= 192:
+    if cin >= 768:  # the fp64 oracle of the widest layer on every golden voxel takes minutes; 192 -> 96 runs untruncated
         coords = coords[:700]
     shape = refcfg.GRID_CART[::-1].tolist()
     ref = sc.Sites(coords, shape)
@@ -211,6 +211,84 @@ def test_inverse_conv_forward_and_backward(dev, golden_dir, monkeypatch, precisi
     out.features.backward(g.float().to(dev))
     assert float((xin.grad.cpu().double() - xc.grad).abs().max()) < tol
     assert float((inv.weight.grad.cpu().double() - w.grad).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
+
+
+_WIDE_ORACLE = {}
+
+
+@pytest.fixture(scope="module")
+def headline_sites(dev):
+    """The first 60 000 voxels (first-seen order) of the headline scene: enough rows (>= 51 200 = 400 row tiles) for the
+    192-column instantiation spconv_split_kernel<12, 2, false> that dominates the benchmark, small enough for the fp64
+    oracle (pairs, not rows x 27, set its cost)."""
+    from oracle import index_ops, sparse_conv as sc
+    from openseg3d_amd import scene
+    coords, _ = index_ops.voxelize(scene.make_scene(0), refcfg.CART_VOXEL, refcfg.CART_RANGE)
+    coords = np.pad(coords[:60000], ((0, 0), (1, 0))).astype(np.int32)
+    shape = refcfg.GRID_CART[::-1].tolist()
+    return coords, shape, sc.Sites(coords, shape)
+
+
+@pytest.mark.parametrize("nbt", [12, 6])
+@pytest.mark.parametrize("cin,cout", [(96, 192), (192, 192), (384, 192)])
+def test_sparse_conv_wide_tiles_at_benchmark_row_counts(dev, headline_sites, cin, cout, nbt):
+    """Value parity of the column-block instantiations the benchmark's deep layers run (NBT = 12: cout % 192 == 0 and
+    >= 400 row tiles; NBT = 6: the 96-column tiles of the 19 k / 7 k-row levels), on >= 51 200 rows, for the submanifold,
+    strided and inverse forms with their parity-ordered tables, forward + input gradient + weight gradient vs the fp64
+    oracle.  Same tolerances as test_sparse_conv_forward_and_backward (split-bf16: ~2^-16 relative per product)."""
+    from oracle import sparse_conv as sc
+    from openseg3d_amd import ops, spconv
+    coords, shape, ref = headline_sites
+    m = coords.shape[0]
+    assert m >= 51200
+    coarse_ref, _, _ = ref.down()
+    torch.manual_seed(cin * 7 + cout)
+    w = torch.randn(cout, 3, 3, 3, cin, dtype=torch.float64) / (27 * cin) ** 0.5
+    gen = torch.Generator().manual_seed(11)
+
+    def oracle(kind, x):
+        key = (kind, cin, cout)
+        if key in _WIDE_ORACLE:  # the fp64 results are shared by the NBT variants of a shape (same seeds below)
+            return _WIDE_ORACLE[key]
+        _WIDE_ORACLE[key] = res = _oracle(kind, x)
+        return res
+
+    def _oracle(kind, x):
+        xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y = {"subm": lambda: sc.subm_conv(xr, ref, wr), "down": lambda: sc.strided_conv(xr, ref, wr)[0],
+             "up": lambda: sc.inverse_conv(xr, ref, wr)}[kind]()
+        g = torch.randn(y.shape, dtype=torch.float64, generator=gen)
+        y.backward(g)
+        return y.detach(), g, xr.grad, wr.grad
+
+    fine = spconv.SparseConvTensor(torch.zeros(m, 16, device=dev), torch.from_numpy(coords).to(dev), shape, 1)
+    down16 = spconv.SparseConv3d(16, 16, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev)
+    with torch.no_grad():
+        mid = down16(fine)  # registers the level pair under indice_key "d"
+    assert np.array_equal(_np(mid.indices), coarse_ref.coords)
+    ops.debug_set_conv_nbt(nbt)
+    try:
+        for kind in ("subm", "down", "up"):
+            rows_in = coarse_ref.coords.shape[0] if kind == "up" else m
+            x = torch.randn(rows_in, cin, dtype=torch.float64, generator=torch.Generator().manual_seed(len(kind) + cin))
+            y_ref, g, dx_ref, dw_ref = oracle(kind, x)
+            if kind == "subm":
+                conv, src = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False).to(dev), fine
+            elif kind == "down":
+                conv, src = spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev), fine
+            else:
+                conv, src = spconv.SparseInverseConv3d(cin, cout, 3, bias=False, indice_key="d").to(dev), mid
+            with torch.no_grad():
+                conv.weight.copy_(w.float())
+            xin = x.float().to(dev).requires_grad_()
+            out = conv(src.replace_feature(xin))
+            assert float((out.features.detach().cpu().double() - y_ref).abs().max()) < 1e-4, kind
+            out.features.backward(g.float().to(dev))
+            assert float((xin.grad.cpu().double() - dx_ref).abs().max()) < 1e-4, kind
+            scale = max(1.0, float(dw_ref.abs().max()))
+            assert float((conv.weight.grad.cpu().double() - dw_ref).abs().max()) < 1e-4 * scale, kind
+    finally:
+        ops.debug_set_conv_nbt(0)
 
 
 # ------------------------------------------------------------------------------------------ a13-a18
