@@ -304,6 +304,21 @@ def main():
                   for g in groups]
     pts_per_step = [int(o[-1]) for o in offsets]  # points that receive logits
 
+    # logit parity + CPU baseline on the weights the run starts from (seed 0), before anything is timed
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_cpu = args.cpu_points if args.cpu_points >= 0 else (150000 if args.workload == "dense2m" else 0)
+        sample, s_cur, s_img = scenes_np[0], n_cur[0], None
+        if args.workload == "multi_sweeps":  # whole scene: the history sweeps and the image rows belong together
+            s_img = images[0][: n_cur[0]]
+        elif n_cpu:
+            sample = sample[:n_cpu]
+            s_cur = sample.shape[0]
+        model.eval()
+        report, o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
+        baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids))
+        del o_res
+
     train = args.mode == "fwdbwd"
     net = model
     if train and distributed:  # tools/train.py:246-247, 276-279
@@ -393,16 +408,16 @@ def main():
             "conv_layers": [{k: l[k] for k in ("rows", "cin", "cout", "us", "bound", "frac")} for l in per_layer],
             "attention_roofline": ATTENTION_REPORT if args.segmentor == "segformer" else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            n_cpu = args.cpu_points if args.cpu_points >= 0 else (150000 if args.workload == "dense2m" else 0)
-            sample, s_cur, s_img = scenes_np[0], n_cur[0], None
-            if args.workload == "multi_sweeps":  # whole scene: the history sweeps and the image rows belong together
-                s_img = images[0][: n_cur[0]]
-            elif n_cpu:
-                sample = sample[:n_cpu]
-                s_cur = sample.shape[0]
-            out["cpu_baseline"], o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
-            out["parity"] = parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids)
+        if baseline is not None:
+            out["cpu_baseline"], out["parity"] = baseline
+            # the trained module against a fresh module loaded from its state_dict: every cached operand (packed weights,
+            # folded BatchNorm affines) must have followed the optimizer (fused optimizers do not bump Tensor._version)
+            fresh = segformer.build_segmentor(cfg, ds).to(dev).eval()
+            fresh.load_state_dict(model.state_dict())
+            with torch.no_grad():
+                a = model(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0]))
+                c = fresh(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0]))
+            out["parity"]["trained_vs_reloaded_max_abs_diff"] = float((a["point_out"] - c["point_out"]).abs().max())
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
             json.dump(per_layer, f, indent=1)

@@ -219,6 +219,32 @@ def _precision_flag():
     raise _lib.Seg3dError(f"SEG3D_CONV_PRECISION must be 'bf16x3' or 'fp32', got {CONV_PRECISION!r}")
 
 
+# ---- when is a cached operand stale?  A tensor's ``_version`` counts in-place autograd-visible writes (copy_,
+# load_state_dict, foreach optimizers) but NOT the fused optimizers (torch._fused_sgd_ / _fused_adamw_ update the
+# parameters without touching the counter) nor writes through ``.data``.  Every cache below therefore keys on
+# (version, WEIGHT_EPOCH): the epoch is bumped by a global optimizer post-step hook -- any torch optimizer, fused or
+# not -- and by invalidate_weight_caches() for code that writes parameters behind autograd's back.
+_WEIGHT_EPOCH = [0]
+
+
+def invalidate_weight_caches():
+    """Call after changing parameters in a way neither ``Tensor._version`` nor an optimizer step reveals (writes
+    through ``.data``, raw pointers): every packed / folded operand is rebuilt at its next use."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def _stamp(t):
+    return (t._version, _WEIGHT_EPOCH[0])
+
+
+def _register_optimizer_hook():
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    register_optimizer_step_post_hook(lambda *_: invalidate_weight_caches())
+
+
+_register_optimizer_hook()
+
+
 # ---- pack registry: every (parameter [slice], operand form) that has been packed once is remembered; when a pack
 # is requested and the parameter has changed since (every optimizer step in training), ALL stale packs are
 # refreshed by one seg3d_pack_weights_batched launch instead of ~220 small ones per step.
@@ -244,10 +270,10 @@ def _cached_pack(weight, kk, transpose, flip):
                   else _lib.query("seg3d_linear_packed_bytes", cin, cout, job.transpose))
         job.out = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
         job.blocks = (nbytes // 32 + 255) // 256  # one work item = 16 packed bf16 (a lane's hi and lo fragments)
-        job.version = -1
+        job.version = None
         _PACK_JOBS[key] = job
         _PACK_DESC.clear()
-    if job.version != owner._version:
+    if job.version != _stamp(owner):
         _refresh_packs(weight.device)
     return job.out
 
@@ -258,7 +284,7 @@ def _refresh_packs(device):
         owner = job.owner()
         if owner is None:
             dead.append(key)
-        elif job.version != owner._version and job.out.device == device:
+        elif job.version != _stamp(owner) and job.out.device == device:
             stale.append((key, job, owner))
     for key in dead:
         del _PACK_JOBS[key]
@@ -284,7 +310,7 @@ def _refresh_packs(device):
         _PACK_DESC[ident] = hit
     _lib.call("seg3d_pack_weights_batched", _ptr(hit[0]), len(stale), hit[1], _stream())
     for _, job, owner in stale:
-        job.version = owner._version
+        job.version = _stamp(owner)
 
 
 def _registry_ok(weight):
@@ -395,13 +421,13 @@ def _linear_pack_f32(weight, transpose):
     """Exact-fp32 MFMA fragment stream of a Linear weight, cached on the parameter while its version is unchanged."""
     cache = weight.__dict__.setdefault("_seg3d_f32_packs", {})
     hit = cache.get(int(transpose))
-    if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
+    if hit is not None and hit[0] == (_stamp(weight), weight.data_ptr()):
         return hit[1]
     w = _f32c(weight)
     cout, cin = w.shape
     out = torch.empty((_lib.query("seg3d_linear_packed_bytes_f32", cin, cout),), dtype=torch.uint8, device=w.device)
     _lib.call("seg3d_linear_pack_weight_f32", _ptr(w), cin, cout, int(transpose), _ptr(out), _stream())
-    cache[int(transpose)] = ((weight._version, weight.data_ptr()), out)
+    cache[int(transpose)] = ((_stamp(weight), weight.data_ptr()), out)
     return out
 
 
@@ -729,7 +755,7 @@ def bn_eval_affine(bn):
     """(scale, shift, key) with bn(x) = x * scale + shift in eval mode.  Cached on the module, keyed on the tensors'
     versions so that loading a checkpoint invalidates it; training steps reset it (batch_norm_act) because the kernel
     updates the running buffers through raw pointers."""
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+    key = (_stamp(bn.weight), bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr(), bn.running_var.data_ptr(), bn.eps, getattr(bn, "_seg3d_stats_epoch", 0))
     cached = getattr(bn, "_seg3d_eval_affine", None)
     if cached is None or cached[0] != key:

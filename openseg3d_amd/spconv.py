@@ -154,7 +154,7 @@ class _Conv3x3x3(SparseModule):
     def _packed_weight(self):
         """Forward-operand pack, cached while the weight is unchanged (weights are static in eval)."""
         w = self.weight
-        key = (w._version, w.data_ptr(), ops.CONV_PRECISION)
+        key = (ops._stamp(w), w.data_ptr(), ops.CONV_PRECISION)
         if self._packed is None or self._packed[0] != key:
             with torch.no_grad():
                 self._packed = (key, ops.pack_weight(w, ops.PACK_FWD))
@@ -187,7 +187,7 @@ class _Conv3x3x3(SparseModule):
         bias (seg3d_spconv_fwd_act); the fold is cached until the weights or the statistics change."""
         scale, shift, bn_key = ops.bn_eval_affine(bn)
         w = self.weight
-        key = (w._version, w.data_ptr(), None if self.bias is None else self.bias._version, bn_key)
+        key = (ops._stamp(w), w.data_ptr(), None if self.bias is None else self.bias._version, bn_key)
         if self._folded is None or self._folded[0] != key:
             with torch.no_grad():
                 wf = (w * scale.view(-1, 1, 1, 1, 1)).contiguous()

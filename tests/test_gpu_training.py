@@ -168,3 +168,37 @@ def test_headline_scene_logits_match_oracle():
     assert par["voxel_ids_bit_exact"] is True and par["rulebook_bit_exact"] is True
     assert par["max_abs_logit_diff"] < 1e-3, par
     assert par["max_abs_voxel_logit_diff"] < 1e-3 and par["max_abs_aux_logit_diff"] < 1e-3, par
+
+
+def test_eval_after_fused_optimizer_step_sees_the_new_weights():
+    """torch's fused optimizers update parameters without bumping Tensor._version; the packed / folded operands cached by
+    the conv, Linear and BatchNorm wrappers must follow them anyway (ops._stamp: version + optimizer-step epoch).
+    Trained module in eval mode == a fresh module loaded from its state_dict, bit for bit."""
+    from openseg3d_amd import batch as B, config, scene, segformer
+    dev = torch.device("cuda:0")
+    cfg = config.default_cfg()
+    ds = config.DatasetSpec(cfg)
+    torch.manual_seed(3)
+    model = segformer.build_segmentor(cfg, ds).to(dev)
+    samples = [scene.make_small_scene(21, 7000, extent=9.0)]
+    ce = torch.nn.functional.cross_entropy
+    for fused in (True, False):
+        opt = torch.optim.SGD(model.parameters(), lr=0.02, momentum=0.9, fused=fused)
+        model.eval()
+        with torch.no_grad():
+            model(B.make_batch(samples, ds.voxel_size, ds.point_cloud_range))  # fills every eval-mode cache
+        model.train()
+        for _ in range(2):
+            b = B.make_batch(samples, ds.voxel_size, ds.point_cloud_range)
+            lab = torch.arange(b["points"].shape[0], device=dev) % 22
+            opt.zero_grad(set_to_none=True)
+            res = model(b)
+            (ce(res["point_out"], lab) + res["voxel_out"].square().mean() + res["aux_voxel_out"].square().mean()).backward()
+            opt.step()
+        fresh = segformer.build_segmentor(cfg, ds).to(dev).eval()
+        fresh.load_state_dict(model.state_dict())
+        model.eval()
+        with torch.no_grad():
+            a = model(B.make_batch(samples, ds.voxel_size, ds.point_cloud_range))["point_out"]
+            c = fresh(B.make_batch(samples, ds.voxel_size, ds.point_cloud_range))["point_out"]
+        assert torch.equal(a, c), (fused, float((a - c).abs().max()))

@@ -125,3 +125,19 @@ def test_synthetic_scene_is_waymo_shaped_and_seeded():
     coors, ids = index_ops.voxelize(a, refcfg.CART_VOXEL, refcfg.CART_RANGE)
     assert 60_000 < coors.shape[0] < 140_000 and (ids >= 0).mean() > 0.95
     assert scene.cart2polar_rows(a).shape == (a.shape[0], 8)
+
+
+def test_optimizer_steps_invalidate_weight_caches():
+    """Fused optimizers leave Tensor._version alone: the operand caches key on ops._stamp = (version, optimizer epoch)."""
+    import torch
+    from openseg3d_amd import ops
+    for fused in (True, False):
+        p = torch.nn.Parameter(torch.randn(4, 4))
+        opt = torch.optim.SGD([p], lr=0.1, momentum=0.9, fused=fused)
+        before = ops._stamp(p)
+        p.grad = torch.ones_like(p)
+        opt.step()
+        assert ops._stamp(p) != before, fused
+    before = ops._stamp(p)
+    ops.invalidate_weight_caches()
+    assert ops._stamp(p) != before
