@@ -265,7 +265,7 @@ def main():
     distributed = dist.is_available() and dist.is_initialized()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    from openseg3d_amd import batch as B, config, scene, segformer
+    from openseg3d_amd import batch as B, config, losses as _losses, ops as _ops, scene, segformer
     dev = torch.device("cuda", local)
     cfg = config.default_cfg()  # == configs/waymo_one_sweep.yaml for every key the model path reads
     if args.workload == "cylinder":  # configs/waymo_one_sweep_cylinder.yaml:2-4
@@ -291,10 +291,9 @@ def main():
         scenes_np, n_cur = [m[0] for m in made], [m[1] for m in made]
     else:
         make = scene.make_dense_scene if args.workload == "dense2m" else scene.make_scene
-        scenes_np = [make(s) for s in seeds]
-        if args.workload == "cylinder":
-            scenes_np = [scene.cart2polar_rows(s) for s in scenes_np]
+        scenes_np = [make(s) for s in seeds]  # cylinder: cartesian rows stay resident, cart2polar runs in the step
         n_cur = [s.shape[0] for s in scenes_np]
+    cyl = args.workload == "cylinder"
     groups = [list(range(i * args.batch, (i + 1) * args.batch)) for i in range(n_scenes)]
     resident = [B.collate_points([scenes_np[j] for j in g], dev) for g in groups]
     offsets = [np.cumsum([n_cur[j] for j in g]).tolist() for g in groups]  # cumulative current-sweep rows
@@ -314,6 +313,9 @@ def main():
         elif n_cpu:
             sample = sample[:n_cpu]
             s_cur = sample.shape[0]
+        if cyl:  # the oracle takes the polar rows the device built: numpy's atan2f differs from any other libm's in the
+            # last bit (tests/test_gpu_parity.py::test_cart2polar_matches_reference), which would move a few boundary points
+            sample = _ops.cart2polar(torch.from_numpy(sample).to(dev)).cpu().numpy()
         model.eval()
         report, o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
         baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids))
@@ -329,7 +331,6 @@ def main():
     opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4,
                           fused=os.environ.get("SEG3D_BENCH_FOREACH_SGD", "0") != "1")
     labels = [torch.randint(0, 22, (n,), device=dev) for n in pts_per_step]
-    from openseg3d_amd import losses as _losses, ops as _ops
     if args.criterion == "ce":
         cfg.MODEL.LOSSES = {"ce": 1.0}
     criterion = _losses.build_criterion(cfg, ds)  # builder.py:26-40
@@ -338,20 +339,20 @@ def main():
     # up inside the step, as tools/train.py:86-104 does
     voxel_labels = []
     for j in range(len(resident)):
-        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j], cyl)
         cur = torch.nonzero(b["points"][:, 4] == 0).view(-1) if args.workload == "multi_sweeps" else None
         voxel_labels.append(_ops.prepare_voxel_labels(b["point_voxel_ids"], labels[j], b["voxel_coords"].shape[0],
                                                       ignore_index=ds.ignore_index, cur_point_indices=cur).long())
 
     def fwd_step(i):
         j = i % len(resident)
-        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j], cyl)
         with torch.no_grad():
             return model(b)
 
     def train_step(i):
         j = i % len(resident)
-        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j])
+        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j], cyl)
         opt.zero_grad(set_to_none=True)
         res = net(b)
         data = {"point_labels": labels[j], "voxel_labels": voxel_labels[j], "batch_size": b["batch_size"]}
@@ -383,7 +384,7 @@ def main():
     out = None
     if rank == 0:
         model.eval()
-        b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0])
+        b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0], cyl)
         roof, per_layer = conv_roofline(model, b0, dev)
         if train:
             step_desc = "fwd + criterion (" + "+".join(cfg.MODEL.LOSSES) + " on 3 heads) + bwd + SGD step"
@@ -415,8 +416,8 @@ def main():
             fresh = segformer.build_segmentor(cfg, ds).to(dev).eval()
             fresh.load_state_dict(model.state_dict())
             with torch.no_grad():
-                a = model(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0]))
-                c = fresh(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0]))
+                a = model(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0], cyl))
+                c = fresh(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0], cyl))
             out["parity"]["trained_vs_reloaded_max_abs_diff"] = float((a["point_out"] - c["point_out"]).abs().max())
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:

@@ -82,6 +82,19 @@ int seg3d_voxelize_f64(const double* points, int64_t n_points, int32_t row_strid
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a3  cart2polar -- seg3d/utils/pointops_utils.py:8-11, wired into the cylinder configs at
+ *     seg3d/datasets/waymo_dataset.py:270-273: rows [.., x, y, z, f..] -> [.., rho, phi, z, x, y, f..]
+ *     (row_stride + 2 columns; the `xyz_col` columns in front -- the batch index of a collated tensor -- are
+ *     copied).  rho = sqrt(x*x + y*y) in the point dtype, bit-identical to numpy; phi = atan2(y, x): float32 rows
+ *     get the double-precision result rounded once, float64 rows the device library's atan2 (numpy takes the host
+ *     libm's atan2f / atan2, documented at 1 ulp: that column of the reference is machine-dependent in its last bit).
+ */
+int seg3d_cart2polar_f32(const float* points, int64_t n_points, int32_t row_stride, int32_t xyz_col,
+                         float* out /* [n_points, row_stride + 2] */, void* stream);
+int seg3d_cart2polar_f64(const double* points, int64_t n_points, int32_t row_stride, int32_t xyz_col,
+                         double* out /* [n_points, row_stride + 2] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * a14  ingroup_inds_ext.forward(group_inds, out_inds) -- seg3d/ops/ingroup_inds/src/
  *      ingroup_inds.cpp:28-48, ingroup_inds_cuda.cu:12-25 (+ the CSR the callers rebuild from it).
  * Rank of every element inside its group.  The reference hands ranks out in atomic arrival

@@ -25,6 +25,8 @@ SIGNATURES = {
     "seg3d_voxelize_workspace_bytes": (_sz, [_i64]),
     "seg3d_voxelize_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "seg3d_voxelize_f64": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "seg3d_cart2polar_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "seg3d_cart2polar_f64": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "seg3d_group_index_workspace_bytes": (_sz, [_i64, _i64]),
     "seg3d_group_index": (ctypes.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "seg3d_coord_hash_bytes": (_sz, [_i64]),

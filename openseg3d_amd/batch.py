@@ -18,10 +18,13 @@ def collate_points(samples, device):
     return pts.to(device=device)
 
 
-def batch_from_resident(points, row_offsets, voxel_size, point_cloud_range, image_features=None):
+def batch_from_resident(points, row_offsets, voxel_size, point_cloud_range, image_features=None, cylinder=False):
     """points: collated [sum N, 1+D] tensor already in HBM; row_offsets: cumulative rows per sample (ints) --
     for multi-sweep batches the cumulative CURRENT-sweep rows (collate_batch's cur_point_count,
-    waymo_dataset.py:367-373); image_features: optional [sum N_current, 28] tensor."""
+    waymo_dataset.py:367-373); image_features: optional [sum N_current, 28] tensor; cylinder: the rows are cartesian and
+    DATASET.USE_CYLINDER is set -- cart2polar runs on the device in front of the voxelizer (waymo_dataset.py:270-275)."""
+    if cylinder:
+        points = ops.cart2polar(points, xyz_col=1)
     coords, ids = ops.voxelize(points, voxel_size, point_cloud_range, xyz_col=1, batch_col=0)
     extra = {} if image_features is None else {"point_image_features": image_features}
     return {
@@ -36,7 +39,7 @@ def batch_from_resident(points, row_offsets, voxel_size, point_cloud_range, imag
     }
 
 
-def make_batch(samples, voxel_size, point_cloud_range, device="cuda"):
+def make_batch(samples, voxel_size, point_cloud_range, device="cuda", cylinder=False):
     pts = collate_points(samples, device)
     offsets = np.cumsum([s.shape[0] for s in samples]).tolist()
-    return batch_from_resident(pts, offsets, voxel_size, point_cloud_range)
+    return batch_from_resident(pts, offsets, voxel_size, point_cloud_range, cylinder=cylinder)

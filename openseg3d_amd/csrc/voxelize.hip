@@ -170,9 +170,57 @@ int voxelize_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_co
     return SEG3D_OK;
 }
 
+// a3: cart2polar (seg3d/utils/pointops_utils.py:8-11) + the row re-assembly of waymo_dataset.py:270-273.
+// One thread per point.  rho = sqrt(x*x + y*y): two roundings of the products, one of the sum, IEEE sqrt -- the same
+// operations numpy performs in the point dtype (-ffp-contract=off: no fused multiply-add).  phi: numpy calls the host
+// libm's atan2f / atan2, which is NOT correctly rounded (glibc documents 1 ulp), so "bit-exact with the reference" is
+// machine-dependent for this one column; here float32 phi is atan2 evaluated in double and rounded once (correctly
+// rounded float32 but for double-rounding ties), float64 phi is the device library's atan2.
+__device__ __forceinline__ float atan2_t(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float sqrt_t(float v) { return sqrtf(v); }
+__device__ __forceinline__ double sqrt_t(double v) { return sqrt(v); }
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void cart2polar_rows(const T* __restrict__ pts, int64_t n, int row_stride, int xyz_col,
+                                                            T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const T* row = pts + i * row_stride;
+    T* o = out + i * (row_stride + 2);
+    for (int j = 0; j < xyz_col; ++j) o[j] = row[j];  // batch-index column(s) in front of the coordinates
+    const T x = row[xyz_col], y = row[xyz_col + 1], z = row[xyz_col + 2];
+    o[xyz_col] = sqrt_t(x * x + y * y);
+    o[xyz_col + 1] = atan2_t(y, x);
+    o[xyz_col + 2] = z;
+    o[xyz_col + 3] = x;
+    o[xyz_col + 4] = y;
+    for (int j = xyz_col + 3; j < row_stride; ++j) o[j + 2] = row[j];
+}
+
+template <typename T>
+int cart2polar_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_col, T* out, void* stream) {
+    if (n < 0 || row_stride < 3 || xyz_col < 0 || xyz_col + 3 > row_stride) return SEG3D_EINVAL;
+    if (n == 0) return SEG3D_OK;
+    if (!points || !out) return SEG3D_EINVAL;
+    hipLaunchKernelGGL(cart2polar_rows<T>, dim3((unsigned)ceil_div64(n, kThreads)), dim3(kThreads), 0, as_stream(stream), points, n,
+                       row_stride, xyz_col, out);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int seg3d_cart2polar_f32(const float* points, int64_t n_points, int32_t row_stride, int32_t xyz_col, float* out, void* stream) {
+    return cart2polar_impl<float>(points, n_points, row_stride, xyz_col, out, stream);
+}
+
+int seg3d_cart2polar_f64(const double* points, int64_t n_points, int32_t row_stride, int32_t xyz_col, double* out,
+                         void* stream) {
+    return cart2polar_impl<double>(points, n_points, row_stride, xyz_col, out, stream);
+}
 
 int seg3d_abi_version(void) { return 29; }
 

@@ -87,6 +87,20 @@ def voxelize(points, voxel_size, point_cloud_range, xyz_col=0, batch_col=-1):
     return coords[:m], ids
 
 
+def cart2polar(points, xyz_col=0):
+    """``cart2polar`` + the row re-assembly of the cylinder configs (pointops_utils.py:8-11, waymo_dataset.py:270-273)
+    on the device: float32/float64 [N, D] rows [.., x, y, z, f..] -> [N, D + 2] rows [.., rho, phi, z, x, y, f..]."""
+    _need_gpu(points)
+    if points.dim() != 2 or points.dtype not in (torch.float32, torch.float64):
+        raise _lib.Seg3dError("points must be a float32/float64 [N, D] tensor")
+    points = points.contiguous()
+    n, d = points.shape
+    out = torch.empty((n, d + 2), dtype=points.dtype, device=points.device)
+    fn = "seg3d_cart2polar_f32" if points.dtype == torch.float32 else "seg3d_cart2polar_f64"
+    _lib.call(fn, _ptr(points), n, d, int(xyz_col), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------ a14
 def group_index(group_ids, n_groups, rank=True, order=True, offsets=True):
     """Deterministic in-group rank and CSR of ``group_ids`` (int32 [n], -1 = skip)."""

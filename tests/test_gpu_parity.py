@@ -41,6 +41,27 @@ def test_voxelize_bit_exact_vs_reference(dev, golden_dir, tag, rng, vs, dt):
     assert ops.grid_size(vs, rng) == d[tag + "_grid"].tolist()
 
 
+def test_cart2polar_matches_reference(dev, golden_dir):
+    """a3 on the device vs the reference's cart2polar (pointops_utils.py:8-11) + row assembly (waymo_dataset.py:270-273):
+    rho and every copied column bit-exact; phi within 1 ulp (float32: the double-precision atan2 rounded once; numpy
+    takes the host libm's atan2f, itself documented at 1 ulp) / 2 ulp (float64)."""
+    from openseg3d_amd import ops
+    d = np.load(os.path.join(golden_dir, "cart2polar.npz"))
+    for dt, ulps in (("float32", 1), ("float64", 2)):
+        pts, want = d[dt + "_points"], d[dt + "_rows"]
+        got = _np(ops.cart2polar(torch.from_numpy(pts).to(dev)))
+        assert got.dtype == want.dtype and got.shape == want.shape
+        for col in (0, 2, 3, 4, 5, 6, 7):
+            assert np.array_equal(got[:, col], want[:, col]), col
+        phi_err = np.abs(got[:, 1].astype(np.float64) - want[:, 1].astype(np.float64))
+        assert (phi_err <= ulps * np.spacing(np.abs(want[:, 1]))).all(), float(phi_err.max())
+        assert np.array_equal(np.signbit(got[:, 1]), np.signbit(want[:, 1]))  # atan2(-0, -2.5) = -pi etc.
+    # collated form: the batch-index column in front is carried along
+    col = torch.from_numpy(np.pad(d["float32_points"], ((0, 0), (1, 0)), constant_values=3.0)).to(dev)
+    got = _np(ops.cart2polar(col, xyz_col=1))
+    assert (got[:, 0] == 3.0).all() and np.array_equal(got[:, [1, 3, 4, 5]], d["float32_rows"][:, [0, 2, 3, 4]])
+
+
 def test_voxelize_batched_matches_per_sample_collate(dev):
     from oracle import index_ops
     from openseg3d_amd import batch, scene

@@ -141,3 +141,33 @@ def test_optimizer_steps_invalidate_weight_caches():
     before = ops._stamp(p)
     ops.invalidate_weight_caches()
     assert ops._stamp(p) != before
+
+
+def test_spconv_checkpoint_layout_converter():
+    """Both spconv weight layouts are recognised by shape; RSCK -> KRSC -> load round-trips (the layouts themselves are
+    unverifiable offline: openseg3d_amd/checkpoint.py)."""
+    import torch
+    from openseg3d_amd import checkpoint, config, segformer
+    cfg = config.default_cfg()
+    torch.manual_seed(1)
+    model = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    rsck = {("module." + k): (v.permute(1, 2, 3, 4, 0).contiguous() if v.dim() == 5 else v) for k, v in sd.items()}
+    n_conv = sum(v.dim() == 5 for v in sd.values())
+    assert n_conv == 20  # 14 submanifold + 3 strided + 3 inverse convs (pointtransformer.py:132-179)
+    other = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+    res = checkpoint.load_reference_checkpoint(other, {"model": rsck, "epoch": 3})
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in other.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    same = checkpoint.convert_spconv_state_dict(sd, model)  # already KRSC: untouched
+    assert all(same[k] is sd[k] for k in sd)
+    bad = dict(sd)
+    key = "point_transformer.conv_input.0.weight"
+    bad[key] = sd[key].permute(0, 4, 1, 2, 3).contiguous()
+    try:
+        checkpoint.convert_spconv_state_dict(bad, model)
+    except ValueError as e:
+        assert "neither KRSC" in str(e)
+    else:
+        raise AssertionError("a weight in neither layout must be refused")

@@ -193,3 +193,15 @@ def test_oracle_prepare_voxel_labels_follows_the_reference_loop():
     for v, c in counters.items():
         want[v] = np.argmax(c)
     assert np.array_equal(index_ops.prepare_voxel_labels(ids, lab, m), want)
+
+
+def test_cart2polar_rows_match_reference(golden_dir):
+    """a3: the host helper that builds the cylinder-config rows against the reference's own cart2polar +
+    waymo_dataset.py:270-273 concatenation (tests/golden/cart2polar.npz, generated by make_golden.py)."""
+    import numpy as np
+    from openseg3d_amd import scene
+    d = np.load(os.path.join(golden_dir, "cart2polar.npz"))
+    for dt in ("float32", "float64"):
+        rows = scene.cart2polar_rows(d[dt + "_points"])
+        assert rows.dtype == d[dt + "_rows"].dtype
+        assert np.array_equal(rows, d[dt + "_rows"])
