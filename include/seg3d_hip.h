@@ -240,9 +240,9 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
  *   tok      voxel rows grouped by window (ascending window id, ascending row inside)
  *   win_start/win_count [<= min(m, canvas)]  CSR of the non-empty windows into tok
  *   win_tile0 [<= min(m, canvas)]  first 32-token tile of each window in the 32-padded token space
- *   tile_item [<= m/32 + windows][2]  (window, tile) work items of the attention prepare pass
- *   qg_item   [<= m/16 + windows][2]  (window, 16-query group) work items of the attention core
- *   counts   device int32[4]: {non-empty windows, voxels with slot == -1, 32-token tiles, 16-query groups}
+ *   tile_item [<= m/32 + windows][2]  (window, 32-token tile) work items of the attention kernels
+ *   qg_item   [<= m/16 + windows][2]  (window, 128-query chunk = 4 tiles) work items of the wide-head attention forward
+ *   counts   device int32[4]: {non-empty windows, voxels with slot == -1, 32-token tiles, 128-query chunks}
  */
 size_t seg3d_window_partition_workspace_bytes(int64_t m, int32_t batch_size, const int32_t* nwin_xyz);
 int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
@@ -272,9 +272,13 @@ int seg3d_pos_embed(const int32_t* in_win, int64_t m, const int32_t* win_xyz /*h
  *   (log-sum-exp per query row, kept for the backward).  m = number of voxel rows; dh in {6,12,24,48}
  *   (8 heads on 48/96/192/384 channels, pointtransformer.py:141-157).
  * Forward runs on the matrix cores in split-bf16 arithmetic (q, k, v, P as bf16 hi + lo, three
- * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate and softmax): a prepare pass per 32-token tile
- * (tile_item) and one wave per (16-query group, head) (qg_item); n_tiles / n_qgroups are counts[2..3] of
- * seg3d_window_partition.
+ * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate and softmax) in ONE launch per layer: a workgroup per
+ * (32-query tile, all 8 heads) for dh 6 / 12 (tile_item) or per (128-query chunk, head) for dh 24 / 48 (qg_item)
+ * gathers, normalises and splits the window's k / v rows itself, 32 keys at a time, through LDS;
+ * n_tiles / n_qgroups are counts[2..3] of seg3d_window_partition.
+ * dropout_p / dropout_seed: attention-probability dropout of training mode (cosine_msa.py:172-174); 0 = none.
+ * The mask is a function of (seed, window, head, query, key) only -- the backward is given the same two values
+ * and regenerates it.  Drop probability is rounded to a multiple of 1/256 and compensated exactly.
  * Backward takes the forward's out and lse, returns gradients w.r.t. the raw q, k, v (through the
  * normalisation) and stores the tau gradient in dtau[0] (per-wave partials in the workspace, summed in a
  * fixed order: the whole backward is free of atomics and identical from run to run).
@@ -285,15 +289,16 @@ int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_
                           const int32_t* win_count, const int32_t* win_tile0,
                           const int32_t* tile_item, int32_t n_tiles, const int32_t* qg_item,
                           int32_t n_qgroups, int64_t m, int32_t n_windows, int32_t heads, int32_t dh,
-                          const float* tau, float tau_min, float* out, float* lse, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          const float* tau, float tau_min, float dropout_p, uint64_t dropout_seed, float* out,
+                          float* lse, void* workspace, size_t workspace_bytes, void* stream);
 int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
                           int32_t ldv, const float* out, const float* dout, const float* lse,
                           const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
                           const int32_t* win_tile0, const int32_t* tile_item, int32_t n_tiles,
                           const int32_t* qg_item, int32_t n_qgroups, int64_t m, int32_t n_windows,
                           int32_t heads, int32_t dh, const float* tau,
-                          float tau_min, float* dq, float* dk, float* dv, int32_t lddq, int32_t lddk,
+                          float tau_min, float dropout_p, uint64_t dropout_seed, float* dq, float* dk,
+                          float* dv, int32_t lddq, int32_t lddk,
                           int32_t lddv, float* dtau, void* workspace, size_t workspace_bytes,
                           void* stream);
 

@@ -16,6 +16,7 @@ REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
 ABI_VERSION = 29
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); must match include/seg3d_hip.h (tests/test_boundary.py cross-checks the names)
 SIGNATURES = {
@@ -57,10 +58,10 @@ SIGNATURES = {
     "seg3d_pos_embed": (ctypes.c_int, [_p, _i64, _p, _p, _i32, _p, _p]),
     "seg3d_window_attn_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "seg3d_window_attn_fwd": (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _i32,
-                                             _i64, _i32, _i32, _i32, _p, _f, _p, _p, _p, _sz, _p]),
+                                             _i64, _i32, _i32, _i32, _p, _f, _f, _u64, _p, _p, _p, _sz, _p]),
     "seg3d_window_attn_bwd": (ctypes.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
-                                             _i32, _i64, _i32, _i32, _i32, _p, _f, _p, _p, _p, _i32, _i32, _i32, _p,
-                                             _p, _sz, _p]),
+                                             _i32, _i64, _i32, _i32, _i32, _p, _f, _f, _u64, _p, _p, _p, _i32, _i32, _i32,
+                                             _p, _p, _sz, _p]),
     "seg3d_layernorm_fwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _f, _i64, _i32, _p, _p, _p, _p]),
     "seg3d_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_i64, _i32]),
     "seg3d_layernorm_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, ctypes.c_size_t, _p]),

@@ -975,9 +975,12 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
                           const float* out, const float* dout, const float* lse, const int32_t* tok,
                           const int32_t* win_start, const int32_t* win_count, const int32_t* win_tile0,
                           const int32_t* tile_item, int32_t n_tiles, const int32_t* qg_item, int32_t n_qgroups, int64_t m,
-                          int32_t n_windows, int32_t heads, int32_t dh, const float* tau, float tau_min, float* dq,
-                          float* dk, float* dv, int32_t lddq, int32_t lddk, int32_t lddv, float* dtau, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          int32_t n_windows, int32_t heads, int32_t dh, const float* tau, float tau_min, float dropout_p,
+                          uint64_t dropout_seed, float* dq, float* dk, float* dv, int32_t lddq, int32_t lddk, int32_t lddv,
+                          float* dtau, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return SEG3D_EINVAL;
+    if (dropout_p > 0.f) return SEG3D_EINVAL;  // TODO(dropout): mask regeneration in the backward passes
+    (void)dropout_seed;
     if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) {
         if (dtau) SEG3D_CHECK_HIP(hipMemsetAsync(dtau, 0, sizeof(float), as_stream(stream)));
         return SEG3D_OK;

@@ -28,6 +28,16 @@ bool attn_small_supported(int heads, int dh);
 int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
                           const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles,
                           int heads, int dh, const float* tau, float tau_min, float* out, float* lse, hipStream_t st);
+// attention_fused.hip: one launch per layer (gather + normalise + split fused into the MFMA core), dropout-capable
+bool attn_fused_supported(int heads, int dh);
+int attn_fused_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+                          const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles,
+                          const int32_t* chunk_item, int n_chunks, int heads, int dh, const float* tau, float tau_min,
+                          float* out, float* lse, float dropout_p, uint64_t seed, hipStream_t st);
+bool attn_use_fused(int heads, int dh) {
+    static const bool off = getenv("SEG3D_ATTN_FUSED") && atoi(getenv("SEG3D_ATTN_FUSED")) == 0;  // A/B switch
+    return !off && attn_fused_supported(heads, dh);
+}
 bool attn_use_small(int heads, int dh) {
     static const bool mfma_only = getenv("SEG3D_ATTN_MFMA_ONLY") != nullptr;  // A/B switch for profiling
     return !mfma_only && attn_small_supported(heads, dh);
@@ -668,12 +678,22 @@ extern "C" int seg3d_window_attn_fwd(const float* q, const float* k, const float
                                      const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
                                      const int32_t* win_tile0, const int32_t* tile_item, int32_t n_tiles,
                                      const int32_t* qg_item, int32_t n_qgroups, int64_t m, int32_t n_windows,
-                                     int32_t heads, int32_t dh, const float* tau, float tau_min, float* out, float* lse,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     int32_t heads, int32_t dh, const float* tau, float tau_min, float dropout_p,
+                                     uint64_t dropout_seed, float* out, float* lse, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) return SEG3D_OK;
     if (!q || !k || !v || !tok || !win_start || !win_count || !win_tile0 || !tile_item || !qg_item || m < 0 ||
-        n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !out || !workspace)
+        n_windows < 0 || n_tiles < 0 || n_qgroups < 0 || heads <= 0 || heads > 16 || !tau || !out || !workspace ||
+        !(dropout_p >= 0.f && dropout_p < 1.f))
         return SEG3D_EINVAL;
+    if (attn_use_fused(heads, dh)) {
+        if (((ldq | ldk | ldv) & 3) ||
+            ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15))
+            return SEG3D_EINVAL;
+        return attn_fused_fwd_launch(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, tile_item, n_tiles, qg_item, n_qgroups,
+                                     heads, dh, tau, tau_min, out, lse, dropout_p, dropout_seed, as_stream(stream));
+    }
+    if (dropout_p > 0.f) return SEG3D_EINVAL;  // only the fused kernels carry the dropout mask
     if (attn_use_small(heads, dh)) {
         if (((ldq | ldk | ldv) & 3) ||
             ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15))

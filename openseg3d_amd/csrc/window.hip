@@ -90,14 +90,14 @@ __global__ __launch_bounds__(kThreads) void win_per_voxel(const int32_t* __restr
     if (s < 0) atomicAdd(&counts[1], 1);
 }
 
-// per canvas entry: (non-empty, 32-token tiles, 16-token query groups, 0) -- scanned to give every window its
-// compact index, its first tile in the 32-padded token space and its first attention work item
+// per canvas entry: (non-empty, 32-token tiles, 128-token query chunks, 0) -- scanned to give every window its
+// compact index, its first tile in the 32-padded token space and its first attention work items
 __global__ __launch_bounds__(kThreads) void win_geom_flags(const uint32_t* __restrict__ count, int64_t n_canvas,
                                                            uint4* __restrict__ flags) {
     const int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (w >= n_canvas) return;
     const uint32_t n = count[w];
-    flags[w] = make_uint4(n ? 1u : 0u, (n + 31u) >> 5, (n + 15u) >> 4, 0u);
+    flags[w] = make_uint4(n ? 1u : 0u, (n + 31u) >> 5, (n + 127u) >> 7, 0u);
 }
 
 __global__ __launch_bounds__(kThreads) void win_compact(const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs,
@@ -117,12 +117,12 @@ __global__ __launch_bounds__(kThreads) void win_compact(const uint32_t* __restri
         if (tile_item)
             for (uint32_t t = 0; t < ((n + 31u) >> 5); ++t) tile_item[p.y + t] = make_int2((int)cw, (int)t);
         if (qg_item)
-            for (uint32_t q = 0; q < ((n + 15u) >> 4); ++q) qg_item[p.z + q] = make_int2((int)cw, (int)q);
+            for (uint32_t q = 0; q < ((n + 127u) >> 7); ++q) qg_item[p.z + q] = make_int2((int)cw, (int)q);
     }
     if (w == n_canvas - 1) {
         counts[0] = (int32_t)(cw + (n ? 1u : 0u));
         counts[2] = (int32_t)(p.y + ((n + 31u) >> 5));
-        counts[3] = (int32_t)(p.z + ((n + 15u) >> 4));
+        counts[3] = (int32_t)(p.z + ((n + 127u) >> 7));
     }
 }
 

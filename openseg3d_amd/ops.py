@@ -889,7 +889,7 @@ class _WindowAttnFn(torch.autograd.Function):
         _lib.call("seg3d_window_attn_fwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
                   _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0), _ptr(wi.tile_item),
                   int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m, int(wi.n_windows), heads, dh,
-                  _ptr(tau_f), float(tau_min), _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+                  _ptr(tau_f), float(tau_min), 0.0, 0, _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
         ctx.save_for_backward(q, k, v, tau, out, lse)
         ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
         return out
@@ -907,7 +907,7 @@ class _WindowAttnFn(torch.autograd.Function):
         _lib.call("seg3d_window_attn_bwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
                   _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count),
                   _ptr(wi.win_tile0), _ptr(wi.tile_item), int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m,
-                  int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), _ptr(dq), _ptr(dk),
+                  int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), 0.0, 0, _ptr(dq), _ptr(dk),
                   _ptr(dv), c, c, c, _ptr(dtau), _ptr(ws), ws.numel(), _stream())
         return dq, dk, dv, dtau.reshape(tau.shape), None, None, None
 
@@ -918,18 +918,20 @@ class _WindowAttnPackedFn(torch.autograd.Function):
     zero-filled slice gradients of q = qk[:, :C], k = qk[:, C:] and their sum."""
 
     @staticmethod
-    def forward(ctx, qk, v, tau, tau_min, heads, wi):
+    def forward(ctx, qk, v, tau, tau_min, heads, wi, drop_p=0.0, drop_seed=0):
         m, c = v.shape
         dh = c // heads
         dev = v.device
         out = torch.empty((m, c), dtype=torch.float32, device=dev)
         lse = torch.empty((m, heads), dtype=torch.float32, device=dev)
         ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, dh), dev)
+        ctx.drop_p, ctx.drop_seed = drop_p, drop_seed
         kp = ctypes.c_void_p(qk.data_ptr() + 4 * c)
         _lib.call("seg3d_window_attn_fwd", _ptr(qk), kp, _ptr(v), 2 * c, 2 * c, c,
                   _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0), _ptr(wi.tile_item),
                   int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m, int(wi.n_windows), heads, dh,
-                  _ptr(tau.reshape(-1)), float(tau_min), _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+                  _ptr(tau.reshape(-1)), float(tau_min), float(drop_p), int(drop_seed), _ptr(out), _ptr(lse), _ptr(ws),
+                  ws.numel(), _stream())
         ctx.save_for_backward(qk, v, tau, out, lse)
         ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
         return out
@@ -950,18 +952,19 @@ class _WindowAttnPackedFn(torch.autograd.Function):
         _lib.call("seg3d_window_attn_bwd", _ptr(qk), kp, _ptr(v), 2 * c, 2 * c, c,
                   _ptr(out), _ptr(dout), _ptr(lse), _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count),
                   _ptr(wi.win_tile0), _ptr(wi.tile_item), int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m,
-                  int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), _ptr(dqk), dkp,
-                  _ptr(dv), 2 * c, 2 * c, c, _ptr(dtau), _ptr(ws), ws.numel(), _stream())
-        return dqk, dv, dtau.reshape(tau.shape), None, None, None
+                  int(wi.n_windows), heads, c // heads, _ptr(tau.reshape(-1)), float(ctx.tau_min), float(ctx.drop_p),
+                  int(ctx.drop_seed), _ptr(dqk), dkp, _ptr(dv), 2 * c, 2 * c, c, _ptr(dtau), _ptr(ws), ws.numel(), _stream())
+        return dqk, dv, dtau.reshape(tau.shape), None, None, None, None, None
 
 
-def window_attention_packed(qk, v, tau, tau_min, heads, wi):
-    """qk: contiguous float32 [m, 2C] (q | k), v: contiguous float32 [m, C]."""
+def window_attention_packed(qk, v, tau, tau_min, heads, wi, drop_p=0.0, drop_seed=0):
+    """qk: contiguous float32 [m, 2C] (q | k), v: contiguous float32 [m, C].  drop_p / drop_seed: attention-probability
+    dropout of training mode (cosine_msa.py:172-174), mask = f(seed, window, head, query, key)."""
     _need_gpu(qk, v, tau)
     if qk.dtype != torch.float32 or v.dtype != torch.float32 or not qk.is_contiguous() or not v.is_contiguous() \
             or qk.shape[1] != 2 * v.shape[1]:
         raise _lib.Seg3dError("qk must be contiguous float32 [m, 2C] and v contiguous float32 [m, C]")
-    return _WindowAttnPackedFn.apply(qk, v, tau, tau_min, heads, wi)
+    return _WindowAttnPackedFn.apply(qk, v, tau, tau_min, heads, wi, float(drop_p), int(drop_seed))
 
 
 class _AttnInProjFn(torch.autograd.Function):

@@ -1,0 +1,99 @@
+"""Window-attention core (a19-a21) on ragged windows against an fp64 restatement of _scaled_cosine_attention
+(cosine_msa.py:115-177) evaluated per window and head from the CSR: every head width of the model (dh 6 / 12 / 24 / 48),
+window sizes around the 16 / 32 / 128-token tile edges, tau in the fixed-maximum regime, in the online-maximum regime
+(tau < 0.036) and below tau_min (clamped), forward and backward; plus the dropout mask's statistics and determinism."""
+import numpy as np
+import pytest
+import torch
+
+import refcfg
+
+pytestmark = pytest.mark.gpu
+
+WINDOW_SIZES = [1, 2, 15, 16, 17, 31, 32, 33, 64, 100, 129, 257, 300, 640]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def windows(dev):
+    """Voxel coordinates whose shift-0 windows hold exactly WINDOW_SIZES tokens, rows shuffled."""
+    from openseg3d_amd.swformer import SparseWindowPartitionLayer
+    rs = np.random.RandomState(0)
+    rows = []
+    for i, n in enumerate(WINDOW_SIZES):
+        cells = rs.permutation(800)[:n]
+        z, y, x = cells // 100, (cells // 10) % 10, cells % 10
+        rows.append(np.stack([np.zeros(n), z + 8, y + 10 * (1 + i % 3), x + 10 * (1 + i)], axis=1))
+    coords = np.concatenate(rows).astype(np.int32)
+    coords = coords[rs.permutation(coords.shape[0])]
+    part = SparseWindowPartitionLayer(refcfg.BATCHING_INFO[0], refcfg.WINDOW_SHAPE, refcfg.GRID_CART.tolist())
+    plan = part.plan(torch.from_numpy(coords).to(dev), 1, 48)
+    wi = plan.index[0]
+    counts = wi.win_count[: wi.n_windows].cpu().numpy()
+    assert sorted(counts.tolist()) == sorted(WINDOW_SIZES)
+    return wi, coords.shape[0]
+
+
+def reference(qk, v, tau, tau_min, heads, wi, keep=None):
+    """fp64, one (window, head) at a time; keep[(w, h)] = optional [n, n] dropout factor (0 or 1 / keep_prob)."""
+    m, c = v.shape
+    dh = c // heads
+    q, k = qk[:, :c], qk[:, c:]
+    tok = wi.tok.cpu().long()
+    starts, counts = wi.win_start[: wi.n_windows].cpu().tolist(), wi.win_count[: wi.n_windows].cpu().tolist()
+    out = torch.zeros(m, c, dtype=torch.float64)
+    scale = 1.0 / torch.clamp(tau.reshape(()), min=tau_min)
+    pieces = []
+    for w, (s, n) in enumerate(zip(starts, counts)):
+        rows = tok[s:s + n]
+        for h in range(heads):
+            sl = slice(h * dh, (h + 1) * dh)
+            qh = torch.nn.functional.normalize(q[rows][:, sl], dim=-1, eps=1e-12)
+            kh = torch.nn.functional.normalize(k[rows][:, sl], dim=-1, eps=1e-12)
+            p = torch.softmax(qh @ kh.t() * scale, dim=-1)
+            if keep is not None:
+                p = p * keep[(w, h)]
+            pieces.append((rows, sl, p @ v[rows][:, sl]))
+    for rows, sl, o in pieces:
+        out[rows, sl] = out[rows, sl] + o  # index_put on disjoint (rows, head) blocks: differentiable
+    return out
+
+
+@pytest.mark.parametrize("tau", [1.0, 0.2, 0.02, 0.004])
+@pytest.mark.parametrize("dh", [6, 12, 24, 48])
+def test_attention_forward_and_backward_vs_fp64(dev, windows, dh, tau):
+    from openseg3d_amd import ops
+    wi, m = windows
+    heads, c = 8, 8 * dh
+    gen = torch.Generator().manual_seed(dh * 10 + int(tau * 1000))
+    qk = torch.randn(m, 2 * c, generator=gen, dtype=torch.float64)
+    qk[5] *= 1e-3   # short rows exercise the normalisation
+    qk[7] *= 40.0
+    v = torch.randn(m, c, generator=gen, dtype=torch.float64) * 1.5
+    tau_t = torch.full((1, 1, 1), tau, dtype=torch.float64)
+    g = torch.randn(m, c, generator=gen, dtype=torch.float64)
+
+    qk_r, v_r, tau_r = qk.clone().requires_grad_(), v.clone().requires_grad_(), tau_t.clone().requires_grad_()
+    ref = reference(qk_r, v_r, tau_r, 0.01, heads, wi)
+    ref.backward(g)
+
+    qk_g, v_g = qk.float().to(dev).requires_grad_(), v.float().to(dev).requires_grad_()
+    tau_g = tau_t.float().to(dev).requires_grad_()
+    out = ops.window_attention_packed(qk_g, v_g, tau_g, 0.01, heads, wi)
+    # split-bf16 products (~2^-16 relative each); sharp softmax (tau 0.02: scores up to 72 in log2 units) amplifies the
+    # score error by the score scale
+    sharp = 1.0 / max(tau, 0.01)
+    tol = 2e-5 * max(1.0, 0.1 * sharp) * float(v.abs().max())
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < tol
+    out.backward(g.float().to(dev))
+    for got, want, name in ((v_g.grad, v_r.grad, "dv"), (qk_g.grad, qk_r.grad, "dqk"), (tau_g.grad, tau_r.grad, "dtau")):
+        scale = max(1.0, float(want.abs().max()))
+        # dtau is ONE number summed over every (query, key, head) triple with heavy cancellation: 2e-3 relative
+        rel = 2e-3 if name == "dtau" else 3e-4
+        assert float((got.cpu().double() - want).abs().max()) < rel * max(1.0, 0.1 * sharp) * scale, name
+    if tau < 0.01:
+        assert float(tau_g.grad.abs().max()) == 0.0  # clamped: no gradient (torch.clamp)
