@@ -36,8 +36,9 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 template <int DH>
 struct Cfg {
-    static constexpr bool kNarrow = DH <= 12;          // all 8 heads of one 32-query tile per workgroup
-    static constexpr int HG = kNarrow ? 8 : 1;         // heads per workgroup
+    static constexpr bool kNarrow = DH <= 12;          // several heads of one 32-query tile per workgroup
+    static constexpr int HG = kNarrow ? 4 : 1;         // heads per workgroup
+    static constexpr int HPT = HG / 4;                 // narrow: whole heads per staging thread (4 threads per key)
     static constexpr int QT = kNarrow ? 1 : 4;         // 32-query tiles per workgroup
     static constexpr int UW = HG * QT / 4;             // (tile, head) units per wave
     static constexpr int DHS = (DH + 7) / 8 * 8;       // K channels stored per head
@@ -51,9 +52,9 @@ struct Cfg {
     static constexpr int kPlane = 32 * (KRS + VRS);    // one plane (hi or lo) of a staged key tile
     static constexpr int kTile = 2 * kPlane;
     static constexpr int NBUF = kNarrow ? 1 : 2;       // narrow: one buffer, more workgroups per CU
-    static constexpr int CT = kNarrow ? 2 * DH : DH / 4;  // fp32 values a staging thread converts per row
+    static constexpr int CT = kNarrow ? HPT * DH : DH / 4;  // fp32 values a staging thread converts per row
     // waves per SIMD the register allocator must leave room for (measured spill-free points)
-    static constexpr int kWaves = DH == 6 ? 3 : DH == 12 ? 2 : DH == 24 ? 3 : 2;
+    static constexpr int kWaves = DH == 6 ? 4 : DH == 12 ? 4 : DH == 24 ? 4 : 2;
 };
 
 __device__ __forceinline__ float quad_sum(float x) {
@@ -62,6 +63,11 @@ __device__ __forceinline__ float quad_sum(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
     return x;
 }
+
+// 1 / max(|x|, eps) from the sum of squares (F.normalize, cosine_msa.py:152-153): v_rsq_f32 (1 ulp) instead of the
+// correctly rounded sqrt + divide sequences (~40 instructions per key per tile); the operands are then rounded to
+// 16 significant bits anyway
+__device__ __forceinline__ float inv_norm(float ss) { return __builtin_amdgcn_rsqf(fmaxf(ss, kNormEps * kNormEps)); }
 
 // two fp32 -> packed bf16 hi pair and lo pair
 __device__ __forceinline__ void split2(float a, float b, uint32_t* hi, uint32_t* lo) {
@@ -96,19 +102,19 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
     const int st_key = (tid & 127) >> 2, st_part = tid & 3;
     const float* st_src = st_which == 0 ? k : v;
     const int st_ld = st_which == 0 ? ldk : ldv;
-    const int st_col = C::kNarrow ? 2 * st_part * DH : h0 * DH + st_part * CT;  // first channel of this thread's share
+    const int st_col = C::kNarrow ? (h0 + C::HPT * st_part) * DH : h0 * DH + st_part * CT;  // first channel of this thread's share
     float st_reg[CT];
-    auto stage_load = [&](int t) {
+    // token row of this thread's key in tile t: loaded a tile ahead of the rows, so that the row gather is one memory
+    // round trip, not two dependent ones
+    auto load_tok = [&](int t) {
         int kk = t * 32 + st_key;
         kk = kk < n ? kk : n - 1;  // clamped rows are finite and masked by p = 0
-        const float* row = st_src + (int64_t)tok[start + kk] * st_ld + st_col;
-        if constexpr (CT % 4 == 0 && (DH * 4) % 16 == 0) {
-#pragma unroll
-            for (int i = 0; i < CT / 4; ++i) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * i);
-                st_reg[4 * i] = x[0]; st_reg[4 * i + 1] = x[1]; st_reg[4 * i + 2] = x[2]; st_reg[4 * i + 3] = x[3];
-            }
-        } else if constexpr (CT % 4 == 0 && C::kNarrow) {  // dh 6: 12 floats at a 16-B aligned offset (48 B per part)
+        return tok[start + kk];
+    };
+    auto stage_load = [&](int32_t token_row) {
+        const float* row = st_src + (int64_t)token_row * st_ld + st_col;
+        // widest aligned pieces: the share starts at a multiple of CT floats past a 16-B aligned head-group base
+        if constexpr ((CT * 4) % 16 == 0 && (C::kNarrow ? (C::HPT * DH * 4) % 16 == 0 : (DH * 4) % 16 == 0)) {
 #pragma unroll
             for (int i = 0; i < CT / 4; ++i) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * i);
@@ -128,11 +134,11 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
             char* dst = base + st_key * KRS;
             if constexpr (C::kNarrow) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
+                for (int hh = 0; hh < C::HPT; ++hh) {
                     float ss = 0.f;
 #pragma unroll
                     for (int d = 0; d < DH; ++d) ss = fmaf(st_reg[hh * DH + d], st_reg[hh * DH + d], ss);
-                    const float r = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+                    const float r = inv_norm(ss);
                     uint32_t hi[DHS / 2], lo[DHS / 2];
 #pragma unroll
                     for (int i = 0; i < DHS / 2; ++i) {
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
                         const float b = 2 * i + 1 < DH ? st_reg[hh * DH + 2 * i + 1] * r : 0.f;
                         split2(a, b, &hi[i], &lo[i]);
                     }
-                    char* p = dst + ((2 * st_part + hh) * DHS) * 2;
+                    char* p = dst + ((C::HPT * st_part + hh) * DHS) * 2;
 #pragma unroll
                     for (int i = 0; i < DHS / 8; ++i) {
                         *reinterpret_cast<u32x4*>(p + 16 * i) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
 #pragma unroll
                 for (int d = 0; d < CT; ++d) ss = fmaf(st_reg[d], st_reg[d], ss);
                 ss = quad_sum(ss);  // the 4 threads of a key hold a quarter of the head each
-                const float r = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+                const float r = inv_norm(ss);
                 char* p = dst + (st_part * CT) * 2;
 #pragma unroll
                 for (int i = 0; i < CT / 2; ++i) {
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
             char* dst = base + 32 * KRS + st_key * VRS;
             if constexpr (C::kNarrow) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
+                for (int hh = 0; hh < C::HPT; ++hh) {
                     uint32_t hi[VW / 2], lo[VW / 2];
 #pragma unroll
                     for (int i = 0; i < VW / 2; ++i) {
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
                         const float b = 2 * i + 1 < DH ? st_reg[hh * DH + 2 * i + 1] : (2 * i + 1 == DH ? 1.0f : 0.f);
                         split2(a, b, &hi[i], &lo[i]);
                     }
-                    char* p = dst + ((2 * st_part + hh) * VW) * 2;
+                    char* p = dst + ((C::HPT * st_part + hh) * VW) * 2;
 #pragma unroll
                     for (int i = 0; i < VW / 8; ++i) {
                         *reinterpret_cast<u32x4*>(p + 16 * i) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
                 }
             ss += __shfl_xor(ss, 16, SEG3D_WAVE);
             ss += __shfl_xor(ss, 32, SEG3D_WAVE);
-            const float r = qscale / fmaxf(sqrtf(ss), kNormEps);
+            const float r = qscale * inv_norm(ss);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
                 l += __shfl_xor(l, 32, SEG3D_WAVE);
             }
             if (token[un][j] < 0) continue;
-            const float inv = (DROPOUT ? drop.inv_keep : 1.0f) / l;
+            const float inv = (DROPOUT ? drop.inv_keep : 1.0f) * __builtin_amdgcn_rcpf(l);  // 1 ulp; products carry 2^-16
             float* op = out + (int64_t)token[un][j] * (heads * DH) + h * DH;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -396,13 +402,17 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
 
     // ---------------------------------------------------------------- main loop over the window's key tiles
     auto run = [&](auto fixed_tag) {
-        stage_load(0);
+        int32_t tok_next = n_kt > 1 ? load_tok(1) : 0;
+        stage_load(load_tok(0));
         stage_store(0);
         __syncthreads();
         for (int t = 0; t < n_kt; ++t) {
             const bool more = t + 1 < n_kt;
             const int buf = C::NBUF == 2 ? (t & 1) : 0;
-            if (more) stage_load(t + 1);  // in flight while this tile is multiplied
+            if (more) {
+                stage_load(tok_next);  // in flight while this tile is multiplied
+                if (t + 2 < n_kt) tok_next = load_tok(t + 2);
+            }
 #pragma unroll
             for (int un = 0; un < UW; ++un)
                 if (active[un]) tile_step(fixed_tag, un, t, lds + buf * C::kTile);
@@ -439,9 +449,9 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
 
 }  // namespace
 
-// heads per workgroup is 8 for the narrow configuration: other head counts stay on the two-launch kernels
+// the narrow configuration takes 4 heads per workgroup: other head counts stay on the two-launch kernels
 bool attn_fused_supported(int heads, int dh) {
-    if (dh == 6 || dh == 12) return heads == 8;
+    if (dh == 6 || dh == 12) return heads % 4 == 0;
     return dh == 24 || dh == 48;
 }
 
