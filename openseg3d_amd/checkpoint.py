@@ -9,7 +9,7 @@ shipped two memory layouts for them:
 
 ``convert_spconv_state_dict`` recognises either by shape and returns a state_dict in this package's layout.
 
-UNTESTED against a real spconv checkpoint: spconv is a third-party dependency absent from /root/reference and from this
+UNTESTED against a real spconv checkpoint: spconv is a third-party dependency absent from the reference tree and from this
 image (requirements.txt:4, version unpinned), so neither layout -- nor spconv's kernel-offset order (assumed kz-major,
 cross-correlation, as torch's conv3d), nor its tap orientation for SparseInverseConv3d -- can be verified offline.  What
 is tested (tests/test_host_logic.py) is the shape recognition and that the permutation round-trips.

@@ -14,6 +14,7 @@
 //  permuted inside a tile, attn_common.hpp), so nothing moves between lanes and no LDS is used.  Each wave
 //  owns its output rows: no atomics except one float add per wave for the scalar tau gradient.
 #include "attn_common.hpp"
+#include "attn_dropout.hpp"
 
 size_t attn_mfma_workspace_bytes(int n_tiles, int heads, int dh);  // attention_mfma.hip
 bool attn_use_small(int heads, int dh);                            // attention_mfma.hip
@@ -21,7 +22,7 @@ int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ld
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                           const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads, int dh,
                           const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
-                          float* dtau, void* workspace, hipStream_t st);  // attention_small.hip
+                          float* dtau, void* workspace, const DropoutParams& drop, hipStream_t st);  // attention_small.hip
 
 namespace {
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q(BwdWs<DH> ws, 
                                                   const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
                                                   const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
                                                   const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
-                                                  int lddq) {
+                                                  int lddq, DropoutParams drop) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -316,6 +317,16 @@ __global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q(BwdWs<DH> ws, 
                     s_acc = mfma3(k_hi[u][s], k_lo[u][s], q_hi[j][s], q_lo[j][s], s_acc);  // S^T[key][query]
                     p_acc = mfma3(v_hi[u][s], v_lo[u][s], g_hi[j][s], g_lo[j][s], p_acc);  // dP^T[key][query]
                 }
+                if (drop.threshold) {  // dP = D * (dO . v): the forward's dropout factors, regenerated (wave-uniform branch)
+                    const int qi_ = q0 + 16 * j + c16;
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const int kj_ = t * 32 + u * 16 + g * 4 + 2 * r2;
+                        const uint32_t bits = dropout_bits(drop, item.x, h, qi_, kj_);
+                        p_acc[2 * r2] *= dropout_factor(drop, bits, qi_, kj_);
+                        p_acc[2 * r2 + 1] *= dropout_factor(drop, bits, qi_, kj_ + 1);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[j]);
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q_lds(BwdWs<DH> 
                                                   const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
                                                   const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
                                                   const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
-                                                  int lddq) {
+                                                  int lddq, DropoutParams drop) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
     // One workgroup = four consecutive 32-query tiles of ONE window and one head (see attn_core_fwd_lds): the streamed
     // K, V and K^T fragments of a key tile are loaded once per workgroup and shared through LDS.  Grid: one workgroup
@@ -492,6 +503,16 @@ __global__ __launch_bounds__(256, kBwdQWaves<DH>) void attn_bwd_q_lds(BwdWs<DH> 
                     s_acc = mfma3(k_hi[u][s], k_lo[u][s], q_hi[j][s], q_lo[j][s], s_acc);  // S^T[key][query]
                     p_acc = mfma3(v_hi[u][s], v_lo[u][s], g_hi[j][s], g_lo[j][s], p_acc);  // dP^T[key][query]
                 }
+                if (drop.threshold) {  // dP = D * (dO . v): the forward's dropout factors, regenerated (wave-uniform branch)
+                    const int qi_ = q0 + 16 * j + c16;
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const int kj_ = t * 32 + u * 16 + g * 4 + 2 * r2;
+                        const uint32_t bits = dropout_bits(drop, item0.x, h, qi_, kj_);
+                        p_acc[2 * r2] *= dropout_factor(drop, bits, qi_, kj_);
+                        p_acc[2 * r2 + 1] *= dropout_factor(drop, bits, qi_, kj_ + 1);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[j]);
@@ -579,7 +600,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(BwdWs<DH> ws, const float* __
                                                    const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                    const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
                                                    const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
-                                                   float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+                                                   float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                   DropoutParams drop) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -656,12 +678,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(BwdWs<DH> ws, const float* __
                     p_acc = mfma3(g_hi[u][s], g_lo[u][s], v_hi[j][s], v_lo[j][s], p_acc);  // dP[query][key]
                 }
                 // rows of this accumulator: queries 32t + 16u + 4g + r (4 consecutive positions)
+                float dfac[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.threshold) {  // the forward's dropout factors of (query 32t + 16u + 4g + r, key k0 + 16j + c16)
+                    const int kj_ = k0 + 16 * j + c16;
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const int qi_ = t * 32 + u * 16 + g * 4 + 2 * r2;
+                        const uint32_t bits = dropout_bits(drop, item.x, h, qi_, kj_);
+                        dfac[2 * r2] = dropout_factor(drop, bits, qi_, kj_);
+                        dfac[2 * r2 + 1] = dropout_factor(drop, bits, qi_ + 1, kj_);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[u][r]);
                     if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;
-                    pv[u * 4 + r] = p;
-                    dsv[u * 4 + r] = p * (p_acc[r] - dl[u][r]);
+                    pv[u * 4 + r] = p * dfac[r];                              // dV = (D * P)^T dO
+                    dsv[u * 4 + r] = p * (dfac[r] * p_acc[r] - dl[u][r]);     // dS = P * (D * dP - delta)
                 }
             }
             bf16x8 p_hi, p_lo, ds_hi, ds_lo;
@@ -714,7 +747,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds(BwdWs<DH> ws, const float
                                                    const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
                                                    const int32_t* __restrict__ win_count, const int32_t* __restrict__ win_tile0,
                                                    const int2* __restrict__ tile_item, int n_items, int heads, int64_t mpad,
-                                                   float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+                                                   float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                   DropoutParams drop) {
     constexpr int DHS = Geo<DH>::DHS, KS = Geo<DH>::KS, NB = Geo<DH>::NB;
     // One workgroup = four consecutive 32-key tiles of ONE window and one head; the streamed Q, dO, Q^T, dO^T fragments
     // of a query tile are loaded once per workgroup and shared through LDS (see attn_core_fwd_lds).
@@ -841,12 +875,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds(BwdWs<DH> ws, const float
                     p_acc = mfma3(g_hi[u][s], g_lo[u][s], v_hi[j][s], v_lo[j][s], p_acc);  // dP[query][key]
                 }
                 // rows of this accumulator: queries 32t + 16u + 4g + r (4 consecutive positions)
+                float dfac[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.threshold) {  // the forward's dropout factors of (query 32t + 16u + 4g + r, key k0 + 16j + c16)
+                    const int kj_ = k0 + 16 * j + c16;
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const int qi_ = t * 32 + u * 16 + g * 4 + 2 * r2;
+                        const uint32_t bits = dropout_bits(drop, item0.x, h, qi_, kj_);
+                        dfac[2 * r2] = dropout_factor(drop, bits, qi_, kj_);
+                        dfac[2 * r2 + 1] = dropout_factor(drop, bits, qi_ + 1, kj_);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f(s_acc[r] - lq[u][r]);
                     if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;
-                    pv[u * 4 + r] = p;
-                    dsv[u * 4 + r] = p * (p_acc[r] - dl[u][r]);
+                    pv[u * 4 + r] = p * dfac[r];                              // dV = (D * P)^T dO
+                    dsv[u * 4 + r] = p * (dfac[r] * p_acc[r] - dl[u][r]);     // dS = P * (D * dP - delta)
                 }
             }
             bf16x8 p_hi, p_lo, ds_hi, ds_lo;
@@ -905,7 +950,7 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
             const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count,
             const int32_t* win_tile0, const int2* tile_item, int n_tiles, const int2* qg_item, int n_qg, int heads,
             const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, float* dtau,
-            void* workspace, hipStream_t st) {
+            void* workspace, const DropoutParams& drop, hipStream_t st) {
     const int64_t mpad = (int64_t)n_tiles * 32;
     BwdWs<DH> ws(workspace, mpad, heads);
     const int c = heads * DH;
@@ -922,29 +967,29 @@ int run_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, in
     if (lds_env) {
         dim3 grid((unsigned)n_tiles, (unsigned)heads);
         hipLaunchKernelGGL(attn_bwd_q_lds<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0,
-                           tile_item, n_tiles, heads, mpad, tau, tau_min, dq, lddq);
+                           tile_item, n_tiles, heads, mpad, tau, tau_min, dq, lddq, drop);
         SEG3D_CHECK_LAUNCH();
         hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(1024), 0, st, ws.tau_part, (int)(n_tiles * heads), dtau);
         SEG3D_CHECK_LAUNCH();
         if (DH <= 24) {
             hipLaunchKernelGGL(attn_bwd_kv_lds<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0,
-                               tile_item, n_tiles, heads, mpad, dk, lddk, dv, lddv);
+                               tile_item, n_tiles, heads, mpad, dk, lddk, dv, lddv, drop);
         } else {  // dh 48: one wave per SIMD either way, and the 56 KiB LDS image costs more than it saves (211 vs 229 us)
             dim3 grid4((unsigned)((n_tiles + 3) / 4), (unsigned)heads);
             hipLaunchKernelGGL(attn_bwd_kv<DH>, grid4, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0,
-                               tile_item, n_tiles, heads, mpad, dk, lddk, dv, lddv);
+                               tile_item, n_tiles, heads, mpad, dk, lddk, dv, lddv, drop);
         }
         SEG3D_CHECK_LAUNCH();
         return SEG3D_OK;
     }
     dim3 grid((unsigned)((n_tiles + 3) / 4), (unsigned)heads);
     hipLaunchKernelGGL(attn_bwd_q<DH>, grid, dim3(256), 0, st, ws, q, ldq, tok, win_start, win_count, win_tile0, tile_item,
-                       n_tiles, heads, mpad, tau, tau_min, dq, lddq);
+                       n_tiles, heads, mpad, tau, tau_min, dq, lddq, drop);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(tau_reduce, dim3(1), dim3(1024), 0, st, ws.tau_part, (int)(grid.x * 4 * grid.y), dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_kv<DH>, grid, dim3(256), 0, st, ws, k, ldk, tok, win_start, win_count, win_tile0, tile_item,
-                       n_tiles, heads, mpad, dk, lddk, dv, lddv);
+                       n_tiles, heads, mpad, dk, lddk, dv, lddv, drop);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -979,8 +1024,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
                           uint64_t dropout_seed, float* dq, float* dk, float* dv, int32_t lddq, int32_t lddk, int32_t lddv,
                           float* dtau, void* workspace, size_t workspace_bytes, void* stream) {
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return SEG3D_EINVAL;
-    if (dropout_p > 0.f) return SEG3D_EINVAL;  // TODO(dropout): mask regeneration in the backward passes
-    (void)dropout_seed;
+    const DropoutParams drop = make_dropout(dropout_p, dropout_seed);  // same mask as the forward, given the same two values
     if (m == 0 || n_windows == 0 || n_tiles == 0 || n_qgroups == 0) {
         if (dtau) SEG3D_CHECK_HIP(hipMemsetAsync(dtau, 0, sizeof(float), as_stream(stream)));
         return SEG3D_OK;
@@ -996,7 +1040,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
     if (attn_use_small(heads, dh)) {
         if (workspace_bytes < (size_t)n_tiles * sizeof(float)) return SEG3D_EWORKSPACE;
         return attn_small_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
-                                     heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace,
+                                     heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace, drop,
                                      as_stream(stream));
     }
     const size_t need = bwd_bytes(n_tiles, heads, dh);
@@ -1008,7 +1052,7 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
 #define SEG3D_BWD_CASE(D)                                                                                              \
     case D:                                                                                                            \
         return run_bwd<D>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, win_tile0, ti, n_tiles, qi,  \
-                          n_qgroups, heads, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace, st)
+                          n_qgroups, heads, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace, drop, st)
     switch (dh) {
         SEG3D_BWD_CASE(6);
         SEG3D_BWD_CASE(12);

@@ -12,6 +12,7 @@
 // with the gradient through x_hat = x / max(|x|, eps) applied to the thread's own vector at the end.
 // Work items are the (window, 32-token tile) list of seg3d_window_partition; block = 32 tokens x heads threads.
 #include "attn_common.hpp"
+#include "attn_dropout.hpp"
 
 namespace {
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
                                                         const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
                                                         const int2* __restrict__ tile_item, int heads,
                                                         const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
-                                                        int lddq, float* __restrict__ tau_part) {
+                                                        int lddq, float* __restrict__ tau_part, DropoutParams drop) {
     extern __shared__ float smem[];
     const int c = heads * DH;
     float* kbuf = smem;
@@ -254,7 +255,10 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
             const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
             const float s = dot(qn, kk);
             const float p = j < nk ? __builtin_amdgcn_exp2f(s - l2) : 0.f;
-            const float ds = p * (dot(go, vv) - delta);
+            float dpv = dot(go, vv);
+            if (drop.threshold)  // dP = D * (dO . v): the forward's dropout factor of (query qi, key t0 + j), regenerated
+                dpv *= dropout_factor(drop, dropout_bits(drop, item.x, h, qi, t0 + j), qi, t0 + j);
+            const float ds = p * (dpv - delta);
             tau_acc = fmaf(ds, s, tau_acc);
             axpy<DH>(ds, kk, &acc);
         }
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
                                                          const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
                                                          const int2* __restrict__ tile_item, int heads,
                                                          const float* __restrict__ tau, float tau_min, float* __restrict__ dk,
-                                                         int lddk, float* __restrict__ dv, int lddv) {
+                                                         int lddk, float* __restrict__ dv, int lddv, DropoutParams drop) {
     extern __shared__ float smem[];  // q~ [32][c], dO [32][c], (L, delta) [32][heads][2]
     const int c = heads * DH;
     float* qbuf = smem;
@@ -339,8 +343,10 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
             const f32x2 ld = *reinterpret_cast<const f32x2*>(lbuf + (j * heads + h) * 2);
             const float s = dot(qq, kn);
             const float p = j < nq ? __builtin_amdgcn_exp2f(s - ld[0]) : 0.f;
-            const float ds = p * (dot(gg, vv) - ld[1]);
-            axpy<DH>(p, gg, &dv_acc);
+            float dfac = 1.0f;
+            if (drop.threshold) dfac = dropout_factor(drop, dropout_bits(drop, item.x, h, t0 + j, kj), t0 + j, kj);
+            const float ds = p * (dfac * dot(gg, vv) - ld[1]);  // dS = P * (D * dP - delta)
+            axpy<DH>(p * dfac, gg, &dv_acc);                     // dV = (D * P)^T dO
             axpy<DH>(ds, qq, &dk_acc);
         }
     }
@@ -390,16 +396,16 @@ int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int l
                   const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                   const int32_t* win_count, const int2* tile_item, int n_tiles, int heads, const float* tau, float tau_min,
                   float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part,
-                  hipStream_t st) {
+                  const DropoutParams& drop, hipStream_t st) {
     const size_t smem_q = (size_t)2 * kTile * heads * DH * sizeof(float);
     hipLaunchKernelGGL(attn_small_bwd_q<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem_q, st, q, k, v, ldq, ldk, ldv,
-                       out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dq, lddq, tau_part);
+                       out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dq, lddq, tau_part, drop);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(tau_reduce_small, dim3(1), dim3(1024), 0, st, tau_part, n_tiles, dtau);
     SEG3D_CHECK_LAUNCH();
     const size_t smem_kv = smem_q + (size_t)kTile * heads * 2 * sizeof(float);
     hipLaunchKernelGGL(attn_small_bwd_kv<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem_kv, st, q, k, v, ldq, ldk, ldv,
-                       out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dk, lddk, dv, lddv);
+                       out, dout, lse, tok, win_start, win_count, tile_item, heads, tau, tau_min, dk, lddk, dv, lddv, drop);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -422,12 +428,12 @@ int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ld
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                           const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads, int dh,
                           const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
-                          float* dtau, void* workspace, hipStream_t st) {
+                          float* dtau, void* workspace, const DropoutParams& drop, hipStream_t st) {
     const int2* ti = reinterpret_cast<const int2*>(tile_item);
     float* tau_part = static_cast<float*>(workspace);  // n_tiles floats
     if (dh == 6)
         return run_small_bwd<6>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
-                                tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, st);
+                                tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st);
     return run_small_bwd<12>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
-                             tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, st);
+                             tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st);
 }

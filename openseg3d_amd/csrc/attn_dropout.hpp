@@ -50,4 +50,9 @@ __device__ __forceinline__ uint32_t dropout_bits(const DropoutParams& d, int win
 __device__ __forceinline__ bool dropout_dropped(const DropoutParams& d, uint32_t bits, int qi, int kj) {
     return ((bits >> (8 * ((qi & 1) * 2 + (kj & 1)))) & 0xFFu) < d.threshold;
 }
+
+// the factor F.dropout multiplies the probability with: 0 or 1 / keep_prob
+__device__ __forceinline__ float dropout_factor(const DropoutParams& d, uint32_t bits, int qi, int kj) {
+    return dropout_dropped(d, bits, qi, kj) ? 0.0f : d.inv_keep;
+}
 #endif

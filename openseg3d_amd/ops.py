@@ -1063,13 +1063,13 @@ class _EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, w_in, b_in, tau, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, meta):
-        heads, tau_min, wi, eps1, eps2, s1, s2 = meta
+        heads, tau_min, wi, eps1, eps2, s1, s2, drop_p, drop_seed = meta
         x = _f32c(x)
         c = x.shape[1]
         c_in = _Ctx(True, False, True, True)
         qk, v = _AttnInProjFn.forward(c_in, x, pos, w_in, b_in)
         c_at = _Ctx(True, True, True, False, False, False)
-        o = _WindowAttnPackedFn.forward(c_at, qk, v, tau, tau_min, heads, wi)
+        o = _WindowAttnPackedFn.forward(c_at, qk, v, tau, tau_min, heads, wi, drop_p, drop_seed)
         a = _linear_apply(o, _linear_pack(w_out, 0), b_out, c, c)
         c_n1 = _Ctx(True, True, True, True, False, False)
         x1 = _LayerNormResidualFn.forward(c_n1, a, x, g1, be1, eps1, s1)

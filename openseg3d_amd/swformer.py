@@ -12,6 +12,8 @@ What changed underneath (MI355X-first):
     flat2window / window2flat copies in every encoder layer (swformer_utils.py:34-85) do not exist;
   * one device pass per (stage, shift) builds every index with no host sync; the counts the host
     needs (windows per shift) are fetched once per stage;
+  * attention-probability dropout (attn_drop = 0.1, training only) is applied inside the attention kernels from a
+    counter-based mask; the backward regenerates it (csrc/attn_dropout.hpp);
   * activation checkpointing (point_transformer_layer.py:321-337) is not used: 288 GB of HBM holds
     the activations of a 180 k-point scene many times over.
   * in training an encoder layer is ONE autograd node (ops._EncoderLayerFn): in-projection, attention, out-projection,
@@ -141,10 +143,20 @@ class CosineMultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)  # nn.MultiheadAttention._reset_parameters
         nn.init.constant_(self.out_proj.bias, 0.0)
 
-    def forward(self, x, pos, wi):
+    def drop_args(self, seed):
+        """(p, seed) of the attention-probability dropout: F.dropout on the softmax output in training mode only
+        (cosine_msa.py:172-174, 394-395).  The mask is a pure function of (seed, window, head, query, key), regenerated by
+        the backward kernels; ``seed`` comes from torch's CPU generator (SWFormerBlock.forward), so torch.manual_seed
+        makes a step reproducible."""
+        if self.training and self.dropout > 0.0:
+            return float(self.dropout), int(seed)
+        return 0.0, 0
+
+    def forward(self, x, pos, wi, seed=0):
         """x [M, C] flat voxel features, pos [M, C]; q = k = (x + pos) W_qk, v = x W_v (cosine_msa.py:58-63)."""
         qk, v = ops.attn_in_proj(x, pos, self.in_proj_weight, self.in_proj_bias)
-        o = ops.window_attention_packed(qk, v, self.tau, self.tau_min, self.num_heads, wi)
+        drop_p, drop_seed = self.drop_args(seed)
+        o = ops.window_attention_packed(qk, v, self.tau, self.tau_min, self.num_heads, wi, drop_p, drop_seed)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias)
 
 
@@ -153,8 +165,8 @@ class WindowAttention(nn.Module):
         super().__init__()
         self.self_attn = CosineMultiheadAttention(d_model, nhead, dropout=attn_drop, tau_min=tau_min)
 
-    def forward(self, feat_2d, pos, wi):
-        return self.self_attn(feat_2d, pos, wi)
+    def forward(self, feat_2d, pos, wi, seed=0):
+        return self.self_attn(feat_2d, pos, wi, seed)
 
 
 class MLP(nn.Module):
@@ -172,6 +184,11 @@ class MLP(nn.Module):
         if self.drop and self.training:
             x = F.dropout(x, self.drop)
         return x
+
+
+def attention_dropout_seed():
+    """63-bit seed from torch's CPU generator: reproducible under torch.manual_seed, never touches the device."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 def drop_path_scale(x, p):
@@ -205,10 +222,13 @@ class EncoderLayer(nn.Module):
         self.mlp = MLP(d_model, mlp_hidden_dim, drop=drop)
         self.drop_path_rate = float(drop_path_rate)
 
-    def forward(self, x, pos, wi, scales=None):
+    def forward(self, x, pos, wi, scales=None, seed=None):
         """``scales``: optional (s1, s2) per-row DropPath factors made by the enclosing block for all its layers at once;
-        None = draw them here (seg3d/models/layers/drop.py:6-19)."""
+        None = draw them here (seg3d/models/layers/drop.py:6-19).  ``seed``: attention-dropout seed of this layer
+        (None = draw one from torch's CPU generator)."""
         at, mlp = self.win_attn.self_attn, self.mlp
+        if seed is None:
+            seed = attention_dropout_seed() if self.training and at.dropout > 0.0 else 0
         drop = self.training and self.drop_path_rate > 0.0
         s1 = s2 = None
         if drop:
@@ -217,12 +237,12 @@ class EncoderLayer(nn.Module):
         if (FUSED_LAYER and torch.is_grad_enabled() and x.requires_grad and not mlp.drop and at.in_proj_bias is not None
                 and ops.encoder_layer_fits(x, at.embed_dim, mlp.fc1.out_features, at.num_heads)):
             # training: the whole layer is one autograd node (ops._EncoderLayerFn)
-            meta = (at.num_heads, at.tau_min, wi, self.norm1.eps, self.norm2.eps, s1, s2)
+            meta = (at.num_heads, at.tau_min, wi, self.norm1.eps, self.norm2.eps, s1, s2) + at.drop_args(seed)
             return ops._EncoderLayerFn.apply(x, pos, at.in_proj_weight, at.in_proj_bias, at.tau, at.out_proj.weight,
                                              at.out_proj.bias, self.norm1.weight, self.norm1.bias, mlp.fc1.weight,
                                              mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, self.norm2.weight,
                                              self.norm2.bias, meta)
-        a = self.win_attn(x, pos, wi)
+        a = self.win_attn(x, pos, wi, seed)
         # fused residual + LayerNorm; stochastic depth rides in the same pass: x + mask/keep * LN(.)
         x = ops.layer_norm_residual(a, x, self.norm1, rowscale=s1)
         return ops.layer_norm_residual(self.mlp(x), x, self.norm2, rowscale=s2)
@@ -242,9 +262,11 @@ class SWFormerBlock(nn.Module):
         x, plan = voxel_info["voxel_features"], voxel_info["plan"]
         half = int(self.depth / 2)  # first depth//2 layers on the unshifted windows (:321-337)
         scales = self.drop_path_scales(x) if self.training else None
+        # one draw from the CPU generator per block and forward (no device round trip); layer i uses seed + i
+        seed = attention_dropout_seed() if self.training else 0
         for i, layer in enumerate(self.layers):
             s = 0 if i < half else 1
-            x = layer(x, plan.pos[s], plan.index[s], None if scales is None else (scales[2 * i], scales[2 * i + 1]))
+            x = layer(x, plan.pos[s], plan.index[s], None if scales is None else (scales[2 * i], scales[2 * i + 1]), seed + i)
         return x
 
     def drop_path_scales(self, x):

@@ -97,3 +97,92 @@ def test_attention_forward_and_backward_vs_fp64(dev, windows, dh, tau):
         assert float((got.cpu().double() - want).abs().max()) < rel * max(1.0, 0.1 * sharp) * scale, name
     if tau < 0.01:
         assert float(tau_g.grad.abs().max()) == 0.0  # clamped: no gradient (torch.clamp)
+
+
+# ------------------------------------------------------------------------------------------ attention dropout
+def _mix(x):
+    x = x ^ (x >> np.uint32(15))
+    x = ((x & np.uint32(0xFFFFFF)) * np.uint32(0x9E3779) + (x >> np.uint32(24)) * np.uint32(0x85EBCA)).astype(np.uint32)
+    x = x ^ (x >> np.uint32(13))
+    x = ((x & np.uint32(0xFFFFFF)) * np.uint32(0xC2B2AF) + (x >> np.uint32(24)) * np.uint32(0x27D4EB)).astype(np.uint32)
+    return x ^ (x >> np.uint32(16))
+
+
+def dropout_factors(p, seed, window, head, n):
+    """csrc/attn_dropout.hpp restated with numpy uint32 arithmetic: [n, n] factors (0 or 1 / keep_prob) of one (window, head)."""
+    thr = min(max(int(p * 256.0 + 0.5), 1), 255)
+    with np.errstate(over="ignore"):
+        x0 = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(window) * np.uint32(0x9E3779B1))
+        x0 = _mix(np.array([x0 + np.uint32(head) * np.uint32(0x7F4A7C15) + np.uint32(seed >> 32)], dtype=np.uint32))[0]
+        qi, kj = np.meshgrid(np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32), indexing="ij")
+        bits = _mix(x0 ^ (((qi >> np.uint32(1)) << np.uint32(16)) | (kj >> np.uint32(1))))
+        byte = (bits >> (np.uint32(8) * ((qi & np.uint32(1)) * np.uint32(2) + (kj & np.uint32(1))))) & np.uint32(0xFF)
+    return np.where(byte < thr, 0.0, 256.0 / (256.0 - thr))
+
+
+@pytest.mark.parametrize("dh", [6, 12, 24, 48])
+def test_attention_dropout_forward_and_backward_vs_fp64(dev, windows, dh):
+    """Training-mode attention (cosine_msa.py:172-174: dropout on the softmax output) with the kernels' counter-based mask
+    restated on the host: forward and every gradient against fp64 autograd with the SAME mask -- which also proves that the
+    forward and the two backward passes regenerate one and the same mask."""
+    from openseg3d_amd import ops
+    wi, m = windows
+    heads, c, p, seed = 8, 8 * dh, 0.1, 0x1234_5678_9ABC_DEF
+    gen = torch.Generator().manual_seed(dh)
+    qk = torch.randn(m, 2 * c, generator=gen, dtype=torch.float64)
+    v = torch.randn(m, c, generator=gen, dtype=torch.float64)
+    g = torch.randn(m, c, generator=gen, dtype=torch.float64)
+    tau_t = torch.full((1, 1, 1), 0.5, dtype=torch.float64)
+    counts = wi.win_count[: wi.n_windows].cpu().tolist()
+    keep = {(w, h): torch.from_numpy(dropout_factors(p, seed, w, h, n)) for w, n in enumerate(counts) for h in range(heads)}
+    qk_r, v_r, tau_r = qk.clone().requires_grad_(), v.clone().requires_grad_(), tau_t.clone().requires_grad_()
+    ref = reference(qk_r, v_r, tau_r, 0.01, heads, wi, keep)
+    ref.backward(g)
+    qk_g, v_g = qk.float().to(dev).requires_grad_(), v.float().to(dev).requires_grad_()
+    tau_g = tau_t.float().to(dev).requires_grad_()
+    out = ops.window_attention_packed(qk_g, v_g, tau_g, 0.01, heads, wi, p, seed)
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 3e-5 * float(v.abs().max())
+    out.backward(g.float().to(dev))
+    for got, want, name in ((v_g.grad, v_r.grad, "dv"), (qk_g.grad, qk_r.grad, "dqk"), (tau_g.grad, tau_r.grad, "dtau")):
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got.cpu().double() - want).abs().max()) < (2e-3 if name == "dtau" else 3e-4) * scale, name
+
+
+def test_attention_dropout_statistics(dev, windows):
+    """Uniform attention (q = 0 -> every score 0 -> p = 1 / n) over v = 1: out = kept / (n * keep_prob).  The kept mass has
+    mean 1; the drop rate is the 8-bit threshold's 26 / 256; a new seed gives a new mask, the same seed the same mask; eval
+    (p = 0) is untouched."""
+    from openseg3d_amd import ops
+    wi, m = windows
+    heads, c = 8, 192
+    qk = torch.zeros(m, 2 * c, device=dev)
+    v = torch.ones(m, c, device=dev)
+    tau = torch.ones(1, 1, 1, device=dev)
+    with torch.no_grad():
+        base = ops.window_attention_packed(qk, v, tau, 0.01, heads, wi)
+        a = ops.window_attention_packed(qk, v, tau, 0.01, heads, wi, 0.1, 11)
+        a2 = ops.window_attention_packed(qk, v, tau, 0.01, heads, wi, 0.1, 11)
+        b = ops.window_attention_packed(qk, v, tau, 0.01, heads, wi, 0.1, 12)
+    assert float((base - 1.0).abs().max()) < 1e-5
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    # per (token, head) kept fraction, weighted by the window size n: pool over every (query, key, head) triple
+    tok = wi.tok.cpu().long()
+    counts = wi.win_count[: wi.n_windows].cpu().tolist()
+    starts = wi.win_start[: wi.n_windows].cpu().tolist()
+    n_of = torch.zeros(m)
+    for s, n in zip(starts, counts):
+        n_of[tok[s:s + n]] = float(n)
+    keep_prob = 230.0 / 256.0
+    kept = (a.cpu()[:, ::24] * keep_prob * n_of[:, None]).round()  # one channel per head: kept keys of that (query, head)
+    total = float(n_of.sum()) * heads
+    drop_rate = 1.0 - float(kept.sum()) / total
+    sigma = (0.1 * 0.9 / total) ** 0.5
+    assert abs(drop_rate - 26.0 / 256.0) < 5 * sigma, (drop_rate, sigma)
+    # the mean of the kept mass is 1 (F.dropout's 1 / keep_prob scaling, with the threshold's own keep probability)
+    mean = float((a.cpu()[:, ::24] * n_of[:, None]).sum()) / total
+    assert abs(mean - 1.0) < 5 * sigma / keep_prob
+    # bytes of one hash word are not correlated: the two keys of a 2 x 2 block drop independently
+    big = max(range(len(counts)), key=lambda w: counts[w])
+    f = dropout_factors(0.1, 11, big, 0, counts[big]) == 0.0
+    both = float((f[:, 0::2][:, : f.shape[1] // 2] & f[:, 1::2][:, : f.shape[1] // 2]).mean())
+    assert abs(both - (26.0 / 256.0) ** 2) < 0.004
