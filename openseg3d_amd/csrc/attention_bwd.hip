@@ -13,10 +13,22 @@
 //  The accumulator layout of the first two products is exactly the B-operand layout of the last ones (tokens
 //  permuted inside a tile, attn_common.hpp), so nothing moves between lanes and no LDS is used.  Each wave
 //  owns its output rows: no atomics except one float add per wave for the scalar tau gradient.
+#include <cstdlib>
+
 #include "attn_common.hpp"
 #include "attn_dropout.hpp"
 
 size_t attn_mfma_workspace_bytes(int n_tiles, int heads, int dh);  // attention_mfma.hip
+bool attn_use_fused(int heads, int dh);                            // attention_mfma.hip
+struct DropoutParams;
+size_t attn_fused_bwd_workspace_bytes(int n_tiles, int n_chunks, int heads, int dh);  // attention_fused_bwd.hip
+bool attn_fused_bwd_supported(int heads, int dh);                                    // attention_fused_bwd.hip
+int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
+                          const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
+                          const int32_t* win_count, const int32_t* tile_item, int n_tiles, const int32_t* chunk_item,
+                          int n_chunks, int heads, int dh, const float* tau, float tau_min, float* dq, float* dk, float* dv,
+                          int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
+                          hipStream_t st);                          // attention_fused_bwd.hip
 bool attn_use_small(int heads, int dh);                            // attention_mfma.hip
 int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
@@ -1037,7 +1049,16 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
         ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
           reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15))
         return SEG3D_EINVAL;  // rows are gathered / stored in 16-B pieces
-    if (attn_use_small(heads, dh)) {
+    static const bool fused_bwd_off = getenv("SEG3D_ATTN_FUSED_BWD") && atoi(getenv("SEG3D_ATTN_FUSED_BWD")) == 0;  // A/B
+    if (!fused_bwd_off && attn_use_fused(heads, dh) && attn_fused_bwd_supported(heads, dh)) {
+        if (workspace_bytes < attn_fused_bwd_workspace_bytes(n_tiles, n_qgroups, heads, dh)) return SEG3D_EWORKSPACE;
+        return attn_fused_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
+                                     qg_item, n_qgroups, heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau,
+                                     workspace, drop, as_stream(stream));
+    }
+    // narrow heads: the vector-ALU kernels win at dh 6 (364 vs 1552 us per layer on the headline scene), the MFMA passes
+    // at dh 12 (1210 vs 1547 us)
+    if (attn_use_small(heads, dh) && dh < 12) {
         if (workspace_bytes < (size_t)n_tiles * sizeof(float)) return SEG3D_EWORKSPACE;
         return attn_small_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
                                      heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace, drop,

@@ -24,57 +24,12 @@
 // based hash of (seed, window, head, query, key); the backward regenerates the same mask (attn_dropout.hpp).
 #include <type_traits>
 
-#include "attn_common.hpp"
-#include "attn_dropout.hpp"
+#include "attn_fused.hpp"
 
 namespace {
 
 using namespace attn;
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-template <int DH>
-struct Cfg {
-    static constexpr bool kNarrow = DH <= 12;          // several heads of one 32-query tile per workgroup
-    static constexpr int HG = kNarrow ? 4 : 1;         // heads per workgroup
-    static constexpr int HPT = HG / 4;                 // narrow: whole heads per staging thread (4 threads per key)
-    static constexpr int QT = kNarrow ? 1 : 4;         // 32-query tiles per workgroup
-    static constexpr int UW = HG * QT / 4;             // (tile, head) units per wave
-    static constexpr int DHS = (DH + 7) / 8 * 8;       // K channels stored per head
-    static constexpr int KS = (DHS + 31) / 32;         // MFMA k-steps over the head dimension
-    static constexpr bool kOnes = DH % 16 != 0;        // a spare V column holds ones: the row sum rides in the PV product
-    static constexpr int VW = (DH + (kOnes ? 1 : 0) + 15) / 16 * 16;  // V channels stored per head
-    static constexpr int NB = VW / 16;                 // 16-row d-blocks of O^T
-    // LDS row strides in bytes (data + padding chosen so that the fragment reads spread over the banks)
-    static constexpr int KRS = HG * DHS * 2 + (kNarrow ? 16 : (DH == 24 ? 0 : 0));
-    static constexpr int VRS = HG * VW * 2 + (kNarrow ? 32 : (DH == 24 ? 32 : 0));
-    static constexpr int kPlane = 32 * (KRS + VRS);    // one plane (hi or lo) of a staged key tile
-    static constexpr int kTile = 2 * kPlane;
-    static constexpr int NBUF = kNarrow ? 1 : 2;       // narrow: one buffer, more workgroups per CU
-    static constexpr int CT = kNarrow ? HPT * DH : DH / 4;  // fp32 values a staging thread converts per row
-    // waves per SIMD the register allocator must leave room for (measured spill-free points)
-    static constexpr int kWaves = DH == 6 ? 4 : DH == 12 ? 4 : DH == 24 ? 4 : 2;
-};
-
-__device__ __forceinline__ float quad_sum(float x) {
-    // sum over the 4 lanes of a quad (DPP quad_perm xor 1, xor 2)
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
-    return x;
-}
-
-// 1 / max(|x|, eps) from the sum of squares (F.normalize, cosine_msa.py:152-153): v_rsq_f32 (1 ulp) instead of the
-// correctly rounded sqrt + divide sequences (~40 instructions per key per tile); the operands are then rounded to
-// 16 significant bits anyway
-__device__ __forceinline__ float inv_norm(float ss) { return __builtin_amdgcn_rsqf(fmaxf(ss, kNormEps * kNormEps)); }
-
-// two fp32 -> packed bf16 hi pair and lo pair
-__device__ __forceinline__ void split2(float a, float b, uint32_t* hi, uint32_t* lo) {
-    const uint32_t w = pack_bf16(a, b);
-    *hi = w;
-    *lo = pack_bf16(a - __builtin_bit_cast(float, w << 16), b - __builtin_bit_cast(float, w & 0xFFFF0000u));
-}
+using namespace attn_fused;
 
 template <int DH, bool DROPOUT>
 __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(

@@ -1,0 +1,556 @@
+// a19-a21 backward, fused: gradients of the ragged sparse-window cosine attention w.r.t. the raw q, k, v and tau
+// (cosine_msa.py:115-177) in two launches per layer, flash-style recompute from the forward's LSE.
+//
+// The earlier backward made three launches: attn_prepare_bwd wrote seven bf16 hi/lo copies of q, k, v, dO (row-major and
+// tile-transposed) plus LSE / delta through HBM, then a dQ pass and a dK/dV pass read them back.  Here each pass stages
+// what it streams straight from the raw fp32 rows, exactly as the fused forward does (attention_fused.hip): 256 threads
+// gather 32 streamed tokens, normalise / scale / split them and park TWO row-major images in LDS; row fragments come back
+// with ds_read_b128, transposed fragments with ds_read_b64_tr_b16 out of the SAME images -- no transposed copies exist.
+//   pass Q  (MODE 0): stationary = the workgroup's queries (Q~, dO fragments, LSE, delta = <dO, O> in registers);
+//                     streamed keys: images K^ and V.       S^T = K^.Q~^T, dP^T = V.dO^T, dS = P (D dP - delta),
+//                     dQ^^T += K^^T.dS^T (K^^T by tr-read of the K^ image), dtau += <dS, S>
+//   pass KV (MODE 1): stationary = the workgroup's keys (K^, V fragments); streamed queries: images Q~ and dO (+ LSE and
+//                     delta per streamed query in LDS).     S = Q~.K^^T, dP = dO.V^T, dV^T += dO^T.(D P), dK^^T += Q~^T.dS
+// (D = the forward's dropout factors, regenerated from the counter-based mask; ^ = L2-normalised, ~ = times log2e / tau).
+// As in the forward, the accumulator of the first products is the B operand of the last ones (tokens in the permuted order
+// the two tr-reads deliver).  The gradient through the normalisation is applied in the epilogue from the raw row.
+// Every wave owns its output rows; dtau = one plain store per wave, summed in a fixed order: no atomics, bit-reproducible.
+#include <cstdlib>
+
+#include "attn_fused.hpp"
+
+namespace {
+
+using namespace attn;
+using namespace attn_fused;
+
+// gradient through x_hat = x / max(|x|, eps) for the rows a wave owns.  grad[b][r] = d(x_hat)[d = 16 b + 4 g + r] of
+// token column c16; returns d(x) in place.  Every lane of the column takes part in the shuffles.
+template <int DH, int NBQ>
+__device__ __forceinline__ void through_normalise(const float* __restrict__ xrow, int g, f32x4* grad) {
+    float xr[NBQ][4];
+    float nrm = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBQ; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = 16 * b + 4 * g + r;
+            xr[b][r] = d < DH ? xrow[d] : 0.f;
+            // accumulator rows past the head width were fed by whatever lies behind the head in the transposed reads
+            // (a neighbouring head, row padding): they are never stored, and must not reach the projection either
+            if (d >= DH) grad[b][r] = 0.f;
+            nrm = fmaf(xr[b][r], xr[b][r], nrm);
+        }
+    nrm += __shfl_xor(nrm, 16, SEG3D_WAVE);
+    nrm += __shfl_xor(nrm, 32, SEG3D_WAVE);
+    const float len = sqrtf(nrm);
+    const float rinv = 1.0f / fmaxf(len, kNormEps);
+    float proj = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBQ; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xr[b][r] *= rinv;  // x_hat
+            proj = fmaf(xr[b][r], grad[b][r], proj);
+        }
+    proj += __shfl_xor(proj, 16, SEG3D_WAVE);
+    proj += __shfl_xor(proj, 32, SEG3D_WAVE);
+    const bool clamped = len < kNormEps;
+#pragma unroll
+    for (int b = 0; b < NBQ; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) grad[b][r] = clamped ? grad[b][r] * rinv : (grad[b][r] - xr[b][r] * proj) * rinv;
+}
+
+// waves per SIMD the register allocator must leave room for (spill-free points; pass KV holds two accumulator sets)
+template <int DH, int MODE>
+constexpr int kBwdWaves = (DH <= 12 && MODE == 0) ? 3 : 2;
+
+template <int DH, int MODE>
+__global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
+    const float* __restrict__ out, const float* __restrict__ dout, const float* __restrict__ lse,
+    const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
+    const int2* __restrict__ items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq, int lddq,
+    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, float* __restrict__ tau_part, DropoutParams drop) {
+    using C = Cfg<DH>;
+    constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW;
+    constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
+    constexpr int NBQ = (DH + 15) / 16;  // 16-row d-blocks of a gradient
+    static_assert(C::UW == 1, "one (tile, head) unit per wave");
+    __shared__ __attribute__((aligned(16))) char lds[C::NBUF * C::kTile + (MODE == 1 ? C::NBUF * 2 * HG * 32 * 4 : 0)];
+    float* ld_lds = reinterpret_cast<float*>(lds + C::NBUF * C::kTile);  // MODE 1: [buf][L | delta][head][32 tokens]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int2 item = items[blockIdx.x];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int n_t = (n + 31) >> 5;  // 32-token tiles of the window (streamed and stationary alike)
+    const int h0 = blockIdx.y * HG;
+    const int c_all = heads * DH;
+    const float tau_c = fmaxf(tau[0], tau_min);
+    const float qscale = kLog2e / tau_c;
+
+    // ---------------------------------------------------------------- staging role of this thread
+    const int st_which = tid >> 7;  // 0: image A (normalised: K^ or Q~), 1: image B (V or dO)
+    const int st_key = (tid & 127) >> 2, st_part = tid & 3;
+    const float* st_src = MODE == 0 ? (st_which == 0 ? k : v) : (st_which == 0 ? q : dout);
+    const int st_ld = MODE == 0 ? (st_which == 0 ? ldk : ldv) : (st_which == 0 ? ldq : c_all);
+    const int st_col = C::kNarrow ? (h0 + C::HPT * st_part) * DH : h0 * DH + st_part * CT;
+    const float st_scale = MODE == 0 ? 1.0f : qscale;
+    float st_reg[CT], st_out[MODE == 1 ? CT : 1];
+    float st_lse = 0.f;
+    auto load_tok = [&](int t) {
+        int kk = t * 32 + st_key;
+        kk = kk < n ? kk : n - 1;  // clamped rows are finite and masked by p = 0
+        return tok[start + kk];
+    };
+    auto load_row = [&](const float* row, float* dst) {
+        if constexpr ((CT * 4) % 16 == 0 && (C::kNarrow ? (C::HPT * DH * 4) % 16 == 0 : (DH * 4) % 16 == 0)) {
+#pragma unroll
+            for (int i = 0; i < CT / 4; ++i) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * i);
+                dst[4 * i] = x[0]; dst[4 * i + 1] = x[1]; dst[4 * i + 2] = x[2]; dst[4 * i + 3] = x[3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CT / 2; ++i) {
+                const f32x2 x = *reinterpret_cast<const f32x2*>(row + 2 * i);
+                dst[2 * i] = x[0]; dst[2 * i + 1] = x[1];
+            }
+        }
+    };
+    auto stage_load = [&](int32_t token_row) {
+        load_row(st_src + (int64_t)token_row * st_ld + st_col, st_reg);
+        if constexpr (MODE == 1) {
+            if (st_which == 1) {  // delta = <dO, O> and the LSE of the streamed query ride along with its dO row
+                load_row(out + (int64_t)token_row * c_all + st_col, st_out);
+                st_lse = lse[(int64_t)token_row * heads + (C::kNarrow ? h0 + st_part : h0)];
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* base = lds + buf * C::kTile;
+        if (st_which == 0) {  // image A: L2-normalise per head (x scale), split, row-major [token][head][DHS]
+            char* dst = base + st_key * KRS;
+            if constexpr (C::kNarrow) {
+                float ss = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) ss = fmaf(st_reg[d], st_reg[d], ss);
+                const float r = st_scale * inv_norm(ss);
+                uint32_t hi[DHS / 2], lo[DHS / 2];
+#pragma unroll
+                for (int i = 0; i < DHS / 2; ++i) {
+                    const float a = 2 * i < DH ? st_reg[2 * i] * r : 0.f;
+                    const float b = 2 * i + 1 < DH ? st_reg[2 * i + 1] * r : 0.f;
+                    split2(a, b, &hi[i], &lo[i]);
+                }
+                char* p = dst + (st_part * DHS) * 2;
+#pragma unroll
+                for (int i = 0; i < DHS / 8; ++i) {
+                    *reinterpret_cast<u32x4*>(p + 16 * i) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
+                    *reinterpret_cast<u32x4*>(p + C::kPlane + 16 * i) = (u32x4){lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+                }
+            } else {
+                float ss = 0.f;
+#pragma unroll
+                for (int d = 0; d < CT; ++d) ss = fmaf(st_reg[d], st_reg[d], ss);
+                ss = quad_sum(ss);
+                const float r = st_scale * inv_norm(ss);
+                char* p = dst + (st_part * CT) * 2;
+#pragma unroll
+                for (int i = 0; i < CT / 2; ++i) {
+                    uint32_t hi, lo;
+                    split2(st_reg[2 * i] * r, st_reg[2 * i + 1] * r, &hi, &lo);
+                    *reinterpret_cast<uint32_t*>(p + 4 * i) = hi;
+                    *reinterpret_cast<uint32_t*>(p + C::kPlane + 4 * i) = lo;
+                }
+            }
+        } else {  // image B: split only, [token][head][VW]; channels DH .. VW-1 are zero
+            char* dst = base + 32 * KRS + st_key * VRS;
+            if constexpr (C::kNarrow) {
+                uint32_t hi[VW / 2], lo[VW / 2];
+#pragma unroll
+                for (int i = 0; i < VW / 2; ++i) {
+                    const float a = 2 * i < DH ? st_reg[2 * i] : 0.f;
+                    const float b = 2 * i + 1 < DH ? st_reg[2 * i + 1] : 0.f;
+                    split2(a, b, &hi[i], &lo[i]);
+                }
+                char* p = dst + (st_part * VW) * 2;
+#pragma unroll
+                for (int i = 0; i < VW / 8; ++i) {
+                    *reinterpret_cast<u32x4*>(p + 16 * i) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
+                    *reinterpret_cast<u32x4*>(p + C::kPlane + 16 * i) = (u32x4){lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+                }
+            } else {
+                char* p = dst + (st_part * CT) * 2;
+#pragma unroll
+                for (int i = 0; i < CT / 2; ++i) {
+                    uint32_t hi, lo;
+                    split2(st_reg[2 * i], st_reg[2 * i + 1], &hi, &lo);
+                    *reinterpret_cast<uint32_t*>(p + 4 * i) = hi;
+                    *reinterpret_cast<uint32_t*>(p + C::kPlane + 4 * i) = lo;
+                }
+                if (VW > DH && st_part == 3) {
+#pragma unroll
+                    for (int i = 0; i < (VW - DH) / 8; ++i) {
+                        *reinterpret_cast<u32x4*>(dst + DH * 2 + 16 * i) = (u32x4){0u, 0u, 0u, 0u};
+                        *reinterpret_cast<u32x4*>(dst + C::kPlane + DH * 2 + 16 * i) = (u32x4){0u, 0u, 0u, 0u};
+                    }
+                }
+            }
+            if constexpr (MODE == 1) {
+                float dsum = 0.f;
+#pragma unroll
+                for (int d = 0; d < CT; ++d) dsum = fmaf(st_reg[d], st_out[d], dsum);
+                if (!C::kNarrow) dsum = quad_sum(dsum);
+                const int hh = C::kNarrow ? st_part : 0;
+                if (C::kNarrow || st_part == 0) {
+                    float* ld = ld_lds + buf * 2 * HG * 32;
+                    ld[hh * 32 + st_key] = st_lse * kLog2e;
+                    ld[HG * 32 + hh * 32 + st_key] = dsum;
+                }
+            }
+        }
+    };
+
+    // ---------------------------------------------------------------- this wave's (tile, head) unit: stationary side
+    const int n_st_here = min(QT, n_t - item.y * QT);
+    const int unit = wave;
+    const int st_tile = C::kNarrow ? 0 : unit;
+    const int hh = C::kNarrow ? unit : 0;
+    const int h = h0 + hh;
+    const int s0 = (item.y * QT + st_tile) * 32;  // first stationary token of this wave
+    const bool active = st_tile < n_st_here;      // wave-uniform
+    const bool two = n - s0 > 16;                 // the tile's second 16-token group exists (wave-uniform)
+    bf16x8 a_hi[2][KS], a_lo[2][KS], b_hi[2][KS], b_lo[2][KS];  // stationary fragments: MODE 0 (Q~, dO), MODE 1 (K^, V)
+    float lq[2] = {0.f, 0.f}, dl[2] = {0.f, 0.f};                // MODE 0: log2-domain LSE and delta of the lane's queries
+    int32_t token[2];
+    {
+        const float* a_src = MODE == 0 ? q : k;
+        const int a_ld = MODE == 0 ? ldq : ldk;
+        const float* b_src = MODE == 0 ? dout : v;
+        const int b_ld = MODE == 0 ? c_all : ldv;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int si = s0 + 16 * j + c16;
+            const bool have = active && si < n;
+            token[j] = have ? tok[start + si] : -1;
+            const float* arow = a_src + (int64_t)(have ? token[j] : 0) * a_ld + h * DH;
+            const float* brow = b_src + (int64_t)(have ? token[j] : 0) * b_ld + h * DH;
+            const float* orow = out + (int64_t)(have ? token[j] : 0) * c_all + h * DH;
+            float xa[KS][8], xb[KS][8];
+            float ss = 0.f, dsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c0 = 32 * s + 8 * g + 2 * i;
+                    f32x2 av = {0.f, 0.f}, bv = {0.f, 0.f};
+                    if (have && c0 < DH) {
+                        av = *reinterpret_cast<const f32x2*>(arow + c0);
+                        bv = *reinterpret_cast<const f32x2*>(brow + c0);
+                        if constexpr (MODE == 0) {
+                            const f32x2 ov = *reinterpret_cast<const f32x2*>(orow + c0);
+                            dsum = fmaf(bv[0], ov[0], fmaf(bv[1], ov[1], dsum));
+                        }
+                    }
+                    xa[s][2 * i] = av[0]; xa[s][2 * i + 1] = av[1];
+                    xb[s][2 * i] = bv[0]; xb[s][2 * i + 1] = bv[1];
+                    ss = fmaf(av[0], av[0], fmaf(av[1], av[1], ss));
+                }
+            ss += __shfl_xor(ss, 16, SEG3D_WAVE);
+            ss += __shfl_xor(ss, 32, SEG3D_WAVE);
+            const float r = (MODE == 0 ? qscale : 1.0f) * inv_norm(ss);
+            if constexpr (MODE == 0) {
+                dsum += __shfl_xor(dsum, 16, SEG3D_WAVE);
+                dsum += __shfl_xor(dsum, 32, SEG3D_WAVE);
+                dl[j] = dsum;
+                lq[j] = have ? lse[(int64_t)token[j] * heads + h] * kLog2e : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xa[s][i] *= r;
+                split_frag(xa[s], &a_hi[j][s], &a_lo[j][s]);
+                split_frag(xb[s], &b_hi[j][s], &b_lo[j][s]);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- fragment reads of a staged tile
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // row fragment (A operand: token u * 16 + c16, channels 32 s + 8 g .. + 7) of image A / image B
+    auto read_arow = [&](const char* base, int u, int s, bf16x8* hi, bf16x8* lo) {
+        const int c0 = 32 * s + 8 * g;
+        if (c0 < DHS) {
+            const char* p = base + (u * 16 + c16) * KRS + (hh * DHS + c0) * 2;
+            *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+            *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
+        } else {
+            *hi = *lo = __builtin_bit_cast(bf16x8, zero4);
+        }
+    };
+    auto read_brow = [&](const char* base, int u, int s, bf16x8* hi, bf16x8* lo) {
+        const int c0 = 32 * s + 8 * g;
+        if (c0 < VW) {
+            const char* p = base + 32 * KRS + (u * 16 + c16) * VRS + (hh * VW + c0) * 2;
+            *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+            *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
+        } else {
+            *hi = *lo = __builtin_bit_cast(bf16x8, zero4);
+        }
+    };
+    // transposed fragment of d-block b (A operand: row d = 16 b + c16, token slots 8 g .. 8 g + 7 = tokens 4g..4g+3,
+    // 16+4g..16+4g+3) out of a row-major image: two ds_read_b64_tr_b16 per plane, every lane takes part
+    auto read_tr = [&](const char* img, int rs, int col0, bf16x8* hi, bf16x8* lo) {
+        const int qq = c16 >> 2, pp = c16 & 3;
+        const char* p0 = img + (4 * g + qq) * rs + (col0 + 4 * pp) * 2;
+        const char* p1 = p0 + 16 * rs;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + C::kPlane));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1 + C::kPlane));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        *hi = __builtin_bit_cast(bf16x8, (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+        *lo = __builtin_bit_cast(bf16x8, (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
+    };
+
+    f32x4 acc0[2][NBQ], acc1[MODE == 1 ? 2 : 1][NBQ];  // MODE 0: dQ^^T; MODE 1: dK^^T (acc0) and dV^T (acc1)
+    float tau_acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < NBQ; ++b) {
+            acc0[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) acc1[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    // ---------------------------------------------------------------- one streamed tile
+    auto tile_step = [&](int t, int buf) {
+        const char* base = lds + buf * C::kTile;
+        const bool last = t + 1 == n_t;
+        bf16x8 ra_hi[2][KS], ra_lo[2][KS], rb_hi[2][KS], rb_lo[2][KS];  // row fragments of images A and B
+        bf16x8 ta_hi[NBQ], ta_lo[NBQ], tb_hi[MODE == 1 ? NBQ : 1], tb_lo[MODE == 1 ? NBQ : 1];  // transposed fragments
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                read_arow(base, u, s, &ra_hi[u][s], &ra_lo[u][s]);
+                read_brow(base, u, s, &rb_hi[u][s], &rb_lo[u][s]);
+            }
+#pragma unroll
+        for (int b = 0; b < NBQ; ++b) {
+            read_tr(base, KRS, hh * DHS + 16 * b, &ta_hi[b], &ta_lo[b]);
+            if (MODE == 1) read_tr(base + 32 * KRS, VRS, hh * VW + 16 * b, &tb_hi[b], &tb_lo[b]);
+        }
+        f32x4 l4[2], d4[2];
+        if constexpr (MODE == 1) {
+            const float* ld = ld_lds + buf * 2 * HG * 32;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                l4[u] = *reinterpret_cast<const f32x4*>(ld + hh * 32 + u * 16 + 4 * g);
+                d4[u] = *reinterpret_cast<const f32x4*>(ld + HG * 32 + hh * 32 + u * 16 + 4 * g);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !two) break;
+            float pv[8], dsv[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    // MODE 0: S^T[key][query] = K^.Q~^T, dP^T = V.dO^T;  MODE 1: S[query][key] = Q~.K^^T, dP = dO.V^T
+                    s_acc = mfma3(ra_hi[u][s], ra_lo[u][s], a_hi[j][s], a_lo[j][s], s_acc);
+                    p_acc = mfma3(rb_hi[u][s], rb_lo[u][s], b_hi[j][s], b_lo[j][s], p_acc);
+                }
+                float dfac[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.threshold) {  // the forward's dropout factors, regenerated (wave-uniform branch)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const int st_i = s0 + 16 * j + c16, sm_i = t * 32 + u * 16 + 4 * g + 2 * r2;
+                        const int qi_ = MODE == 0 ? st_i : sm_i, kj_ = MODE == 0 ? sm_i : st_i;
+                        const uint32_t bits = dropout_bits(drop, item.x, h, qi_, kj_);
+                        dfac[2 * r2] = dropout_factor(drop, bits, qi_, kj_);
+                        dfac[2 * r2 + 1] = MODE == 0 ? dropout_factor(drop, bits, qi_, kj_ + 1) : dropout_factor(drop, bits, qi_ + 1, kj_);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lrow = MODE == 0 ? lq[j] : l4[u][r];
+                    const float drow = MODE == 0 ? dl[j] : d4[u][r];
+                    float p = __builtin_amdgcn_exp2f(s_acc[r] - lrow);
+                    if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;  // streamed token past the window's end
+                    const float ds = p * (dfac[r] * p_acc[r] - drow);       // dS = P (D dP - delta)
+                    dsv[u * 4 + r] = ds;
+                    if (MODE == 0) tau_acc[j] = fmaf(ds, s_acc[r], tau_acc[j]);
+                    else pv[u * 4 + r] = p * dfac[r];                        // dV = (D P)^T dO
+                }
+            }
+            bf16x8 ds_hi, ds_lo;
+            split_frag(dsv, &ds_hi, &ds_lo);
+#pragma unroll
+            for (int b = 0; b < NBQ; ++b) acc0[j][b] = mfma3(ta_hi[b], ta_lo[b], ds_hi, ds_lo, acc0[j][b]);
+            if constexpr (MODE == 1) {
+                bf16x8 p_hi, p_lo;
+                split_frag(pv, &p_hi, &p_lo);
+#pragma unroll
+                for (int b = 0; b < NBQ; ++b) acc1[j][b] = mfma3(tb_hi[b], tb_lo[b], p_hi, p_lo, acc1[j][b]);
+            }
+        }
+    };
+
+    // ---------------------------------------------------------------- main loop over the window's streamed tiles
+    {
+        int32_t tok_next = n_t > 1 ? load_tok(1) : 0;
+        stage_load(load_tok(0));
+        stage_store(0);
+        __syncthreads();
+        for (int t = 0; t < n_t; ++t) {
+            const bool more = t + 1 < n_t;
+            const int buf = C::NBUF == 2 ? (t & 1) : 0;
+            if (more) {
+                stage_load(tok_next);
+                if (t + 2 < n_t) tok_next = load_tok(t + 2);
+            }
+            if (active) tile_step(t, buf);
+            if (C::NBUF == 1) __syncthreads();
+            if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0);
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    float* tau_slot = tau_part ? tau_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave : nullptr;
+    if (!active) {
+        if (MODE == 0 && lane == 0) *tau_slot = 0.f;
+        return;
+    }
+    float tau_sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const bool valid = token[j] >= 0;
+        const int32_t trow = valid ? token[j] : tok[start];  // invalid columns read a real row and store nothing
+        if constexpr (MODE == 0) {
+            const float inv_tau = 1.0f / tau_c;
+#pragma unroll
+            for (int b = 0; b < NBQ; ++b) acc0[j][b] = acc0[j][b] * inv_tau;
+            if (valid) tau_sum += tau_acc[j];
+            through_normalise<DH, NBQ>(q + (int64_t)trow * ldq + h * DH, g, acc0[j]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NBQ; ++b) acc0[j][b] = acc0[j][b] * kLn2;  // Q~ = q_hat log2e / tau  ->  q_hat / tau = Q~ ln2
+            through_normalise<DH, NBQ>(k + (int64_t)trow * ldk + h * DH, g, acc0[j]);
+        }
+        if (!valid) continue;
+        float* o0 = MODE == 0 ? dq + (int64_t)trow * lddq + h * DH : dk + (int64_t)trow * lddk + h * DH;
+        float* o1 = MODE == 1 ? dv + (int64_t)trow * lddv + h * DH : nullptr;
+#pragma unroll
+        for (int b = 0; b < NBQ; ++b) {
+            const int d = 16 * b + 4 * g;
+            if (DH % 4 == 0) {
+                if (d < DH) {
+                    *reinterpret_cast<f32x4*>(o0 + d) = acc0[j][b];
+                    if (MODE == 1) *reinterpret_cast<f32x4*>(o1 + d) = acc1[j][b];
+                }
+            } else {
+                if (d + 1 < DH) {
+                    *reinterpret_cast<f32x2*>(o0 + d) = (f32x2){acc0[j][b][0], acc0[j][b][1]};
+                    if (MODE == 1) *reinterpret_cast<f32x2*>(o1 + d) = (f32x2){acc1[j][b][0], acc1[j][b][1]};
+                }
+                if (d + 3 < DH) {
+                    *reinterpret_cast<f32x2*>(o0 + d + 2) = (f32x2){acc0[j][b][2], acc0[j][b][3]};
+                    if (MODE == 1) *reinterpret_cast<f32x2*>(o1 + d + 2) = (f32x2){acc1[j][b][2], acc1[j][b][3]};
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        // d/dtau: s_nat = s2 ln2 = c / tau  ->  dL/dtau = -sum(ds s_nat) / tau   (zero while tau is clamped)
+        for (int off = 32; off > 0; off >>= 1) tau_sum += __shfl_xor(tau_sum, off, SEG3D_WAVE);
+        if (lane == 0) *tau_slot = tau[0] > tau_min ? -tau_sum * kLn2 / tau_c : 0.f;
+    }
+}
+
+// dtau = sum of the per-wave partials in a fixed order
+__global__ __launch_bounds__(1024) void tau_reduce_fused(const float* __restrict__ part, int count, float* __restrict__ dtau) {
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;  // independent chains: the loads overlap
+    int i = threadIdx.x;
+    for (; i + 3072 < count; i += 4096) {
+        v0 += part[i];
+        v1 += part[i + 1024];
+        v2 += part[i + 2048];
+        v3 += part[i + 3072];
+    }
+    for (; i < count; i += 1024) v0 += part[i];
+    float v = (v0 + v1) + (v2 + v3);
+    __shared__ float red[16];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, SEG3D_WAVE);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        dtau[0] = t;
+    }
+}
+
+template <int DH>
+int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out, const float* dout,
+           const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count, const int2* tile_item,
+           int n_tiles, const int2* chunk_item, int n_chunks, int heads, const float* tau, float tau_min, float* dq, float* dk,
+           float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part, const DropoutParams& drop, hipStream_t st) {
+    using C = Cfg<DH>;
+    const int2* items = C::kNarrow ? tile_item : chunk_item;
+    const int n_items = C::kNarrow ? n_tiles : n_chunks;
+    const dim3 grid((unsigned)n_items, (unsigned)(heads / C::HG));
+    hipLaunchKernelGGL((attn_fused_bwd<DH, 0>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
+                       win_count, items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, drop);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tau_reduce_fused, dim3(1), dim3(1024), 0, st, tau_part, (int)(grid.x * grid.y * 4), dtau);
+    SEG3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_fused_bwd<DH, 1>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
+                       win_count, items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, drop);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+}  // namespace
+
+// dh 6 stays on the vector-ALU kernels (windows of ~15 voxels: 360 vs 475 us per layer on the headline scene), dh 48 on the
+// three-launch MFMA passes (pass KV would spill); measured per layer: dh 12 1540 -> 617 us, dh 24 780 -> 520 us
+bool attn_fused_bwd_supported(int heads, int dh) {
+    static const bool all = getenv("SEG3D_ATTN_FUSED_BWD_ALL") != nullptr;  // A/B: also dh 6
+    return ((dh == 12 || (all && dh == 6)) && heads % 4 == 0) || dh == 24;
+}
+
+// floats of workspace the fused backward needs (one dtau partial per wave of pass Q)
+size_t attn_fused_bwd_workspace_bytes(int n_tiles, int n_chunks, int heads, int dh) {
+    const size_t items = (dh <= 12) ? (size_t)n_tiles * (heads / 4) : (size_t)n_chunks * heads;
+    return items * 4 * sizeof(float) + 256;
+}
+
+int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
+                          const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
+                          const int32_t* win_count, const int32_t* tile_item, int n_tiles, const int32_t* chunk_item,
+                          int n_chunks, int heads, int dh, const float* tau, float tau_min, float* dq, float* dk, float* dv,
+                          int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
+                          hipStream_t st) {
+    const int2* ti = reinterpret_cast<const int2*>(tile_item);
+    const int2* ci = reinterpret_cast<const int2*>(chunk_item);
+    float* tau_part = static_cast<float*>(workspace);
+#define SEG3D_FB(D)                                                                                                        \
+    case D:                                                                                                                \
+        return launch<D>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, ci, n_chunks, heads, \
+                         tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st)
+    switch (dh) {
+        SEG3D_FB(6);
+        SEG3D_FB(12);
+        SEG3D_FB(24);
+        default: return SEG3D_EINVAL;  // dh 48: pass KV would spill (two 3-block accumulator sets + eight streamed fragments)
+    }
+#undef SEG3D_FB
+}

@@ -43,11 +43,13 @@ def test_voxelize_bit_exact_vs_reference(dev, golden_dir, tag, rng, vs, dt):
 
 def test_cart2polar_matches_reference(dev, golden_dir):
     """a3 on the device vs the reference's cart2polar (pointops_utils.py:8-11) + row assembly (waymo_dataset.py:270-273):
-    rho and every copied column bit-exact; phi within 1 ulp (float32: the double-precision atan2 rounded once; numpy
-    takes the host libm's atan2f, itself documented at 1 ulp) / 2 ulp (float64)."""
+    rho and every copied column bit-exact; phi within 4 ulp for float32: the device value is the double-precision atan2
+    rounded once, i.e. correctly rounded, while numpy's float32 arctan2 (its SIMD loops on the build host) is a <= 4 ulp
+    routine -- 40 % of this fixture's values are not the correctly rounded ones, the farthest by 3 ulp -- so that column of
+    the reference depends on the machine it runs on; float64: two libraries at <= 1 ulp each."""
     from openseg3d_amd import ops
     d = np.load(os.path.join(golden_dir, "cart2polar.npz"))
-    for dt, ulps in (("float32", 1), ("float64", 2)):
+    for dt, ulps in (("float32", 4), ("float64", 2)):
         pts, want = d[dt + "_points"], d[dt + "_rows"]
         got = _np(ops.cart2polar(torch.from_numpy(pts).to(dev)))
         assert got.dtype == want.dtype and got.shape == want.shape
