@@ -172,6 +172,18 @@ int seg3d_spconv_fwd_act(const float* x, const int32_t* nbr, int64_t m_out, int6
                          int32_t pack_flags, const float* bias /*or NULL*/, const float* addend /*or NULL*/,
                          int32_t relu, int32_t cin, int32_t cout, float* y, const int32_t* row_order /*or NULL*/,
                          void* stream);
+/* Wide layers (cin >= 192): the same contract as seg3d_spconv_fwd_act with the operand conversion hoisted out of the
+ * gather-GEMM.  seg3d_spconv_presplit writes x [m_in, cin] once as bf16 hi plane | lo plane ([m_in + 1, cin] each; the
+ * extra row is zero and stands for every inactive table entry) into xs (seg3d_spconv_presplit_bytes);
+ * seg3d_spconv_fwd_presplit then moves rows and weights global -> LDS by LDS-DMA and multiplies: no operand passes
+ * through a vector register before it is an MFMA fragment.  cin % 32 == 0, cout % 96 == 0, split-bf16 packs only.
+ * Same call sites as seg3d_spconv_fwd (spconv_utils.py:13-32, pointtransformer.py:69-113, 159-166). */
+size_t seg3d_spconv_presplit_bytes(int64_t m_in, int32_t cin);
+int seg3d_spconv_presplit(const float* x, int64_t m_in, int32_t cin, void* xs, void* stream);
+int seg3d_spconv_fwd_presplit(const void* xs, const int32_t* nbr, int64_t m_out, int64_t m_in, const void* w_packed,
+                              int32_t pack_flags, const float* bias /*or NULL*/, const float* addend /*or NULL*/,
+                              int32_t relu, int32_t cin, int32_t cout, float* y,
+                              const int32_t* row_order /*or NULL*/, void* stream);
 /* Test hook: force the column-block width (x16 columns) of the split-bf16 gather-GEMM so that every kernel
  * instantiation can be pinned against the oracle at any row count (0 = automatic choice; 1, 2, 3, 4, 6, 12).
  * Same effect as the SEG3D_CONV_NBT environment variable, which is read once when the library loads.

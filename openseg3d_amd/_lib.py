@@ -40,6 +40,9 @@ SIGNATURES = {
     "seg3d_spconv_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_spconv_fwd": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_spconv_fwd_act": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    "seg3d_spconv_presplit_bytes": (_sz, [_i64, _i32]),
+    "seg3d_spconv_presplit": (ctypes.c_int, [_p, _i64, _i32, _p, _p]),
+    "seg3d_spconv_fwd_presplit": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "seg3d_debug_set_conv_nbt": (ctypes.c_int, [_i32]),
     "seg3d_spconv_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "seg3d_spconv_wgrad": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),

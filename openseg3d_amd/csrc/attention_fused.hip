@@ -187,9 +187,16 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
             l_run[un][j] = 0.f;
 #pragma unroll
             for (int b = 0; b < NB; ++b) o_acc[un][j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // a wave without this query group (idle wave of a small window, tile with <= 16 queries) skips the whole
+            // normalise / split prologue: wave-uniform, and those fragments are never multiplied
+            if (!active[un] || (j == 1 && !two[un])) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) q_hi[un][j][s] = q_lo[un][j][s] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                continue;
+            }
             float x[KS][8];
             float ss = 0.f;
-            const bool have = active[un] && qi < n;
+            const bool have = qi < n;
             if (have) token[un][j] = tok[start + qi];
             const float* row = q + (int64_t)(have ? token[un][j] : 0) * ldq + (h0 + hh_of[un]) * DH;
 #pragma unroll

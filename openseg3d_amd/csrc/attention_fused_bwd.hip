@@ -234,7 +234,14 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int si = s0 + 16 * j + c16;
-            const bool have = active && si < n;
+            token[j] = -1;
+            if (!active || (j == 1 && !two)) {  // no such token group: skip the normalise / split prologue (wave-uniform)
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    a_hi[j][s] = a_lo[j][s] = b_hi[j][s] = b_lo[j][s] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                continue;
+            }
+            const bool have = si < n;
             token[j] = have ? tok[start + si] : -1;
             const float* arow = a_src + (int64_t)(have ? token[j] : 0) * a_ld + h * DH;
             const float* brow = b_src + (int64_t)(have ? token[j] : 0) * b_ld + h * DH;

@@ -358,9 +358,31 @@ def debug_set_conv_nbt(nbt):
     _lib.call("seg3d_debug_set_conv_nbt", int(nbt))
 
 
+# Wide layers (cin >= 192), alternative schedule: operands pre-split once per layer, gather-GEMM fed by LDS-DMA
+# (csrc/spconv_dma.hip).  Measured on the headline scene it ties the register-staged kernel (-7 % on the 58 k-row layers,
+# +2 % on the 19 k-row layers including its conversion pass: both are bound by the 1.2 rounds of workgroups those levels
+# give 256 CUs, not by the operand path), so it is opt-in: SEG3D_CONV_DMA=1
+CONV_DMA = os.environ.get("SEG3D_CONV_DMA", "0") == "1"
+
+
+def _conv_dma_fits(packed, cin, cout):
+    return CONV_DMA and (packed.flags & PACK_SPLIT_BF16) and cin >= 192 and cin % 32 == 0 and cout % 96 == 0
+
+
+def _conv_dma(x, nbr, packed, bias, addend, relu, cin, cout, order, y):
+    m_in, m_out = x.shape[0], nbr.shape[1]
+    xs = torch.empty((_lib.query("seg3d_spconv_presplit_bytes", m_in, cin),), dtype=torch.uint8, device=x.device)
+    _lib.call("seg3d_spconv_presplit", _ptr(x), m_in, cin, _ptr(xs), _stream())
+    _lib.call("seg3d_spconv_fwd_presplit", _ptr(xs), _ptr(nbr), m_out, m_in, _ptr(packed.data), packed.flags, _ptr(bias),
+              _ptr(addend), int(bool(relu)), cin, cout, _ptr(y), _ptr(order), _stream())
+    return y
+
+
 def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
+    if _conv_dma_fits(packed, cin, cout):
+        return _conv_dma(x, nbr, packed, bias, None, False, cin, cout, order, y)
     _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
               cin, cout, _ptr(y), _ptr(order), _stream())
     return y
@@ -371,8 +393,11 @@ def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True
     x = _f32c(x)
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
+    addend = None if addend is None else _f32c(addend)
+    if _conv_dma_fits(packed, cin, cout):
+        return _conv_dma(x, nbr, packed, bias, addend, relu, cin, cout, order, y)
     _lib.call("seg3d_spconv_fwd_act", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
-              _ptr(None if addend is None else _f32c(addend)), int(bool(relu)), cin, cout, _ptr(y), _ptr(order), _stream())
+              _ptr(addend), int(bool(relu)), cin, cout, _ptr(y), _ptr(order), _stream())
     return y
 
 
