@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
 MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md:43
-PMC_TRAFFIC_FILES = ("r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json")  # newest first
+PMC_TRAFFIC_FILES = ("r02_pmc_conv_traffic.json",)
 ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
 
 WORKLOADS = {
@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=-1,
                     help="points of the CPU-baseline / parity sample (0 = whole scene; default: whole scene, "
-                         "150000 for dense2m so that the default run stays within minutes)")
+                         "150000 for dense2m and 30000 current-sweep rows for multi_sweeps so that the run stays within minutes)")
     return ap.parse_args()
 
 
@@ -306,10 +306,15 @@ def main():
     # logit parity + CPU baseline on the weights the run starts from (seed 0), before anything is timed
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_cpu = args.cpu_points if args.cpu_points >= 0 else (150000 if args.workload == "dense2m" else 0)
+        # bounded samples (10-30 s of CPU work): the dense scene's first 150 k points; of a multi-sweep scene the first
+        # 30 k current-sweep rows with their image features and twice as many history rows (the oracle's DeepFusion kNN is
+        # a brute-force O(n^2) search: minutes on a whole sweep)
+        n_cpu = args.cpu_points if args.cpu_points >= 0 else {"dense2m": 150000, "multi_sweeps": 30000}.get(args.workload, 0)
         sample, s_cur, s_img = scenes_np[0], n_cur[0], None
-        if args.workload == "multi_sweeps":  # whole scene: the history sweeps and the image rows belong together
-            s_img = images[0][: n_cur[0]]
+        if args.workload == "multi_sweeps":
+            k = min(n_cpu, n_cur[0]) if n_cpu else n_cur[0]
+            sample = np.concatenate([sample[:k], sample[n_cur[0]: n_cur[0] + 2 * k]], axis=0)
+            s_cur, s_img = k, images[0][:k]
         elif n_cpu:
             sample = sample[:n_cpu]
             s_cur = sample.shape[0]
@@ -387,7 +392,8 @@ def main():
         b0 = B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0], cyl)
         roof, per_layer = conv_roofline(model, b0, dev)
         if train:
-            step_desc = "fwd + criterion (" + "+".join(cfg.MODEL.LOSSES) + " on 3 heads) + bwd + SGD step"
+            step_desc = ("fwd (attention dropout p=0.1, DropPath) + criterion (" + "+".join(cfg.MODEL.LOSSES)
+                         + " on 3 heads) + bwd + SGD step")
         else:
             step_desc = "forward-only eval"
         out = {

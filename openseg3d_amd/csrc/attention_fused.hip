@@ -163,6 +163,12 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
         }
     };
 
+    // The first key tile's gather is issued BEFORE the query prologue: its two dependent round trips (token index, then
+    // the rows) overlap those of the queries instead of following them -- these workgroups live for a few microseconds,
+    // most of it memory latency.
+    int32_t tok_next = n_kt > 1 ? load_tok(1) : 0;
+    stage_load(load_tok(0));
+
     // ---------------------------------------------------------------- this wave's (tile, head) units
     const int n_qt_here = min(QT, n_kt - item.y * QT);  // query tiles of the item that exist
     bf16x8 q_hi[UW][2][KS], q_lo[UW][2][KS];
@@ -364,8 +370,6 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
 
     // ---------------------------------------------------------------- main loop over the window's key tiles
     auto run = [&](auto fixed_tag) {
-        int32_t tok_next = n_kt > 1 ? load_tok(1) : 0;
-        stage_load(load_tok(0));
         stage_store(0);
         __syncthreads();
         for (int t = 0; t < n_kt; ++t) {

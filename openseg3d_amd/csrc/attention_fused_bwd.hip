@@ -214,6 +214,10 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         }
     };
 
+    // first streamed tile's gather in flight before the stationary prologue (see attention_fused.hip)
+    int32_t tok_next = n_t > 1 ? load_tok(1) : 0;
+    stage_load(load_tok(0));
+
     // ---------------------------------------------------------------- this wave's (tile, head) unit: stationary side
     const int n_st_here = min(QT, n_t - item.y * QT);
     const int unit = wave;
@@ -411,8 +415,6 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 
     // ---------------------------------------------------------------- main loop over the window's streamed tiles
     {
-        int32_t tok_next = n_t > 1 ? load_tok(1) : 0;
-        stage_load(load_tok(0));
         stage_store(0);
         __syncthreads();
         for (int t = 0; t < n_t; ++t) {

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r2f
+python bench.py > gpurun_out/r2f/default.json 2> gpurun_out/r2f/default.err; echo default rc=$?
+python bench.py --workload dense2m --steps 8 --warmup 3 > gpurun_out/r2f/dense2m.json 2> gpurun_out/r2f/dense2m.err; echo dense rc=$?
+python bench.py --workload cylinder --batch 4 --steps 8 --warmup 3 --scenes 2 > gpurun_out/r2f/cylinder.json 2> gpurun_out/r2f/cylinder.err; echo cyl rc=$?
+python bench.py --workload multi_sweeps --batch 2 --steps 8 --warmup 3 --scenes 2 > gpurun_out/r2f/multi.json 2> gpurun_out/r2f/multi.err; echo ms rc=$?
+python bench.py --segmentor spnet --steps 10 --warmup 3 > gpurun_out/r2f/spnet.json 2> gpurun_out/r2f/spnet.err; echo spnet rc=$?
