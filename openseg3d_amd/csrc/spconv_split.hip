@@ -7,15 +7,19 @@
 // rate.  Effect on the full model: max |logit error| 9e-6 against the 1e-3 budget.
 //
 // Tile: 4 waves x (RB x 16) output rows x (NBT x 16) columns.  Work is a stream of chunks
-// (active kernel offset k, 32 input channels).  An optional row order lets the caller group output rows that share
-// their set of active offsets (strided / inverse convs: the set is fixed by the row's coordinate parity, 1-8 of 27),
-// so that a tile visits only those offsets instead of all 27.  Per chunk the workgroup copies the pre-split W_k fragments
+// (32 input channels, active kernel offset k) -- channel slice OUTERMOST: the rows a tile gathers for its different
+// offsets are largely the same rows (the tile and its halo), so within one channel slice the same 128-B lines are
+// read again a few chunks later and come from the CU's L1 / the XCD's L2 instead of crossing the fabric once per
+// offset (offset-outermost order: 2.4 GB of fabric reads for a 384 -> 384 layer whose operands total 76 MB).
+// The tile's neighbour table (27 x 128 entries) is loaded once into LDS -- the same loads find the offsets that are
+// active at all.  An optional row order lets the caller group output rows that share their set of active offsets
+// (strided / inverse convs: the set is fixed by the row's coordinate parity, 1-8 of 27), so that a tile visits only
+// those offsets instead of all 27.  Per chunk the workgroup copies the pre-split W_k fragments
 // (NBT x 2 KiB, contiguous in the packed stream) straight into a double-buffered LDS slot with
 // register-staged 16-B loads, every wave gathers its neighbour rows (32 B per lane), splits them in
 // registers and issues RB x NBT x 3 v_mfma_f32_16x16x32_bf16.  The W loads and the gather of chunk c+1 are
-// in flight while chunk c computes (their waits sit behind the MFMAs); one barrier per chunk; the table
-// entries of the next offset are loaded one offset ahead.  Offsets with no active
-// neighbour in the whole tile are never visited; a wave whose own rows have none skips gather and MFMAs.
+// in flight while chunk c computes (their waits sit behind the MFMAs); one barrier per chunk.  Offsets with no active
+// neighbour in the whole tile are never visited; a wave whose own rows have none skips the MFMAs.
 #include <atomic>
 #include <cstdlib>
 
@@ -124,6 +128,10 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
     constexpr int kPieces = NBT * 2;  // 1-KiB wave-instructions per chunk
     __shared__ __attribute__((aligned(16))) uint4 wlds[2 * kSlot];
     __shared__ uint32_t wave_mask[kW];
+    // neighbour table of the tile, [wave][offset][row of the wave]: loaded once (the same 27 loads find the active
+    // offsets), read per chunk -- the chunk order below changes the offset every chunk
+    constexpr int kRowsW = RB * 16;
+    __shared__ int32_t idx_lds[DENSE ? 1 : kW * 27 * kRowsW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
     // ---- which offsets does this tile touch?  (27 independent loads, then ballots)
     uint32_t my_mask = 0;
     {
-        const int64_t pos = row0 + (lane & (RB * 16 - 1));  // tile position -> output row (optional processing order)
+        const int64_t pos = row0 + (lane & (kRowsW - 1));  // tile position -> output row (optional processing order)
         const bool ok = pos < m_out;
         const int64_t rc = ok ? (row_order ? (int64_t)row_order[pos] : pos) : last_row;
         if (DENSE) {  // dense rows (Linear layer): one "offset", neighbour of row r is row r
@@ -145,13 +153,16 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 27; ++k) v[k] = nbr[(int64_t)k * m_out + rc];
 #pragma unroll
-            for (int k = 0; k < 27; ++k)
-                if (__ballot(ok && v[k] >= 0) != 0ull) my_mask |= 1u << k;
+            for (int k = 0; k < 27; ++k) {
+                v[k] = ok ? v[k] : -1;
+                if (__ballot(v[k] >= 0) != 0ull) my_mask |= 1u << k;
+                if (lane < kRowsW) idx_lds[(wave * 27 + k) * kRowsW + lane] = v[k];
+            }
         }
     }
     if (lane == 0) wave_mask[wave] = my_mask;
     __syncthreads();
-    uint32_t todo = wave_mask[0] | wave_mask[1] | wave_mask[2] | wave_mask[3];
+    const uint32_t todo_all = wave_mask[0] | wave_mask[1] | wave_mask[2] | wave_mask[3];
 
     f32x4 acc[RB][NBT];
 #pragma unroll
@@ -161,29 +172,24 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         for (int rb = 0; rb < RB; ++rb) acc[rb][n] = (f32x4){b, b, b, b};
     }
 
-    if (todo != 0u) {
-        // rows this lane gathers (clamped so that every load is in bounds; masked afterwards)
-        int64_t grow[RB];
+    if (todo_all != 0u) {
+        // Chunk order: 32-channel slice outermost, offsets inside.  The rows a tile gathers for its different offsets
+        // are mostly the same rows (its own rows and their halo), so for one channel slice they are 128-B lines that
+        // the next offsets read again within a few chunks -- they stay in the CU's L1 / the XCD's L2 instead of coming
+        // over the fabric once per offset (deep levels: x alone is 30 MB per level, 4 MiB of L2 per XCD).
+        int64_t grow[RB];  // DENSE: rows this lane streams (clamped so that every load is in bounds)
         bool grow_ok[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int64_t pos = row0 + rb * 16 + c16;
             grow_ok[rb] = pos < m_out;
-            grow[rb] = grow_ok[rb] ? (row_order ? (int64_t)row_order[pos] : pos) : last_row;
+            grow[rb] = grow_ok[rb] ? pos : last_row;
         }
-        // neighbour rows of offset k for this lane's RB rows (raw loads; the caller decides when to look at them)
+        // neighbour rows of offset k for this lane's RB rows
         auto fetch_idx = [&](int k, int32_t* idx) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) idx[rb] = DENSE ? (int32_t)grow[rb] : nbr[(int64_t)k * m_out + grow[rb]];
-        };
-        auto any_active = [&](int32_t* idx) {
-            bool any = false;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                idx[rb] = grow_ok[rb] ? idx[rb] : -1;
-                any |= idx[rb] >= 0;
-            }
-            return __ballot(any) != 0ull;
+            for (int rb = 0; rb < RB; ++rb)
+                idx[rb] = DENSE ? (grow_ok[rb] ? (int32_t)grow[rb] : -1) : idx_lds[(wave * 27 + k) * kRowsW + rb * 16 + c16];
         };
         // W chunk -> registers now, -> LDS slot after the MFMAs of the current chunk: piece j (1 KiB) belongs to wave
         // j % 4.  (An LDS-DMA copy would save the registers, but the compiler then drains vmcnt before the first
@@ -229,42 +235,37 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             }
         };
 
+        uint32_t todo = todo_all;
         int k_cur = __builtin_ctz(todo);
         todo &= todo - 1;
         int cb_cur = 0;
-        int32_t idx_cur[RB], idx_pre[RB];  // idx_pre: the table entries of the offset after k_cur, loaded one offset ahead
-        fetch_idx(k_cur, idx_cur);
-        bool on_cur = any_active(idx_cur);
-        if (todo != 0u) fetch_idx(__builtin_ctz(todo), idx_pre);
-
-        // prologue: chunk 0
-        stage_w(k_cur, 0);
-        issue_a(idx_cur, 0, on_cur);
+        bool on_cur = (my_mask >> k_cur) & 1u;  // wave-uniform: does any of this wave's rows have a neighbour at k_cur?
+        {
+            int32_t idx0[RB];
+            fetch_idx(k_cur, idx0);
+            // prologue: chunk 0
+            stage_w(k_cur, 0);
+            issue_a(idx0, 0, on_cur);
+        }
         land_a();
         commit_w(0);
         __syncthreads();
 
         int buf = 0;
         for (;;) {
-            int k_nxt = k_cur, cb_nxt = cb_cur + 1;
-            bool have_next = true, on_nxt = on_cur;
-            int32_t idx_nxt[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) idx_nxt[rb] = idx_cur[rb];
-            if (cb_nxt == cb_n) {
-                cb_nxt = 0;
-                if (todo == 0u) {
-                    have_next = false;
-                } else {
-                    k_nxt = __builtin_ctz(todo);
-                    todo &= todo - 1;
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) idx_nxt[rb] = idx_pre[rb];
-                    on_nxt = any_active(idx_nxt);
-                    if (todo != 0u) fetch_idx(__builtin_ctz(todo), idx_pre);
-                }
+            int k_nxt, cb_nxt = cb_cur;
+            bool have_next = true;
+            if (todo == 0u) {  // next channel slice, offsets from the start
+                cb_nxt = cb_cur + 1;
+                todo = todo_all;
+                have_next = cb_nxt < cb_n;
             }
+            k_nxt = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const bool on_nxt = (my_mask >> k_nxt) & 1u;
             if (have_next) {
+                int32_t idx_nxt[RB];
+                fetch_idx(k_nxt, idx_nxt);
                 stage_w(k_nxt, cb_nxt);
                 issue_a(idx_nxt, cb_nxt, on_nxt);
             }
@@ -290,8 +291,6 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             k_cur = k_nxt;
             cb_cur = cb_nxt;
             on_cur = on_nxt;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) idx_cur[rb] = idx_nxt[rb];
         }
     }
 
@@ -365,20 +364,21 @@ static std::atomic<int> g_forced_nbt{[] {
 }()};
 
 extern "C" int seg3d_debug_set_conv_nbt(int32_t nbt) {
-    if (nbt != 0 && nbt != 1 && nbt != 2 && nbt != 3 && nbt != 4 && nbt != 6 && nbt != 12) return SEG3D_EINVAL;
+    if (nbt != 0 && nbt != 1 && nbt != 2 && nbt != 3 && nbt != 4 && nbt != 6 && nbt != 8 && nbt != 12) return SEG3D_EINVAL;
     g_forced_nbt.store(nbt, std::memory_order_relaxed);
     return SEG3D_OK;
 }
 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
-    // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deep levels have few rows
-    // (19k, 7k) and wide channels and run better on twice as many 96-column workgroups (measured per layer,
-    // profiles/README.md); narrower tiles re-gather the rows too often.
+    // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deepest level has few rows
+    // (19k) and 384+ columns: 128-column workgroups put it on the chip in ONE resident round (153 row tiles x 3 = 459 of
+    // 512 slots; 96 columns = 612 = a second, mostly empty round) and gather each row 3 times instead of 4
+    // (measured per layer, profiles/README.md); narrower tiles re-gather the rows too often.
     const int nb = cout / 16;
     const int64_t row_tiles = ceil_div64(m_out, 4 * 2 * 16);
     int pick = 1;
-    if (nb % 12 == 0) pick = row_tiles >= 400 ? 12 : 6;
+    if (nb % 12 == 0) pick = row_tiles >= 400 ? 12 : (nb % 8 == 0 ? 8 : 6);
     else if (nb % 6 == 0) pick = 6;
     else if (nb % 4 == 0) pick = 4;
     else if (nb % 3 == 0) pick = 3;
@@ -386,6 +386,7 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
     if (const int w = g_forced_nbt.load(std::memory_order_relaxed); w > 0 && nb % w == 0) pick = w;
     switch (pick) {
         case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
         case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
         case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
         case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);

@@ -252,11 +252,12 @@ def headline_sites(dev):
     return coords, shape, sc.Sites(coords, shape)
 
 
-@pytest.mark.parametrize("nbt", [12, 6, "dma"])
-@pytest.mark.parametrize("cin,cout", [(96, 192), (192, 192), (384, 192)])
+@pytest.mark.parametrize("cin,cout,nbt", [(cin, cout, nbt) for cin, cout in [(96, 192), (192, 192), (384, 192)]
+                                          for nbt in (12, 6, "dma")] + [(192, 384, 8)])
 def test_sparse_conv_wide_tiles_at_benchmark_row_counts(dev, headline_sites, monkeypatch, cin, cout, nbt):
     """Value parity of the column-block instantiations the benchmark's deep layers run (NBT = 12: cout % 192 == 0 and
-    >= 400 row tiles; NBT = 6: the 96-column tiles of the 19 k / 7 k-row levels), on >= 51 200 rows, for the submanifold,
+    >= 400 row tiles; NBT = 8: the 128-column tiles of the 384-wide 19 k-row level; NBT = 6: 96-column tiles), on
+    >= 51 200 rows, for the submanifold,
     strided and inverse forms with their parity-ordered tables, forward + input gradient + weight gradient vs the fp64
     oracle.  Same tolerances as test_sparse_conv_forward_and_backward (split-bf16: ~2^-16 relative per product)."""
     from oracle import sparse_conv as sc

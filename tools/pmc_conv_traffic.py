@@ -1,4 +1,4 @@
-"""Build profiles/r01_pmc_conv_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+"""Build profiles/r02_pmc_conv_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
 `bench.py --mode fwd --steps 2 --warmup 1 --no-cpu-baseline` and the per-layer list bench.py writes.
 
 usage: python tools/pmc_conv_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <bench_layers.json> <out.json>
