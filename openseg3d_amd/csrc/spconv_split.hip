@@ -25,6 +25,24 @@
 
 #include "common.hpp"
 
+#ifdef SEG3D_CONV_STAMP
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" int seg3d_debug_conv_stamps(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : 2;
+}
+#define STAMP(i)                                                     \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        st_acc[i] += t_ - st_last;                                   \
+        st_last = t_;                                                \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -135,6 +153,11 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
+#ifdef SEG3D_CONV_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
     const int64_t row0 = (int64_t)blockIdx.x * (kW * RB * 16) + wave * (RB * 16);
     const int nb0 = blockIdx.y * NBT;
     const int cb_n = (cin + 31) >> 5, nb_n = cout >> 4;
@@ -252,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         __syncthreads();
 
         int buf = 0;
+        STAMP(7);
         for (;;) {
             int k_nxt, cb_nxt = cb_cur;
             bool have_next = true;
@@ -269,6 +293,10 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                 stage_w(k_nxt, cb_nxt);
                 issue_a(idx_nxt, cb_nxt, on_nxt);
             }
+            // (Issuing these loads between the MFMAs below instead -- one per column block -- is slower: every 1-KiB
+            // wave load holds the wave for 55-80 cycles at the CU's address unit, lanes of a quad read four different
+            // rows; spread over the MFMAs they stall the matrix pipe instead and land later.  tools/probes/conv_stamps.py)
+            STAMP(0);
             if (on_cur) {
                 const uint4* slot = wlds + buf * kSlot;
 #pragma unroll
@@ -283,10 +311,21 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                     }
                 }
             }
+            STAMP(1);
             if (!have_next) break;
+#ifdef SEG3D_CONV_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(2);
+#endif
             land_a();
+            STAMP(3);
             commit_w(buf ^ 1);
+#ifdef SEG3D_CONV_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(4);
+#endif
             __syncthreads();
+            STAMP(5);
             buf ^= 1;
             k_cur = k_nxt;
             cb_cur = cb_nxt;
@@ -294,6 +333,13 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         }
     }
 
+#ifdef SEG3D_CONV_STAMP
+    if (g_stamp_buf && lane == 0) {
+        unsigned long long* o = g_stamp_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
+    }
+#endif
     // D layout of v_mfma_f32_16x16x*: row = (lane>>4)*4 + r, col = lane & 15
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
