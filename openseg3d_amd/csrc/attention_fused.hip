@@ -32,7 +32,7 @@ using namespace attn;
 using namespace attn_fused;
 
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
+__global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>::kWaves)) void attn_fused_fwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
     const int2* __restrict__ items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ out,
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
     int32_t token[UW][2];
     int q0[UW], hh_of[UW];
     bool active[UW], two[UW];
+    uint32_t drop_row[UW][2];  // dropout: hash state of this lane's query pair (attn_dropout.hpp), fixed over the key loop
 #pragma unroll
     for (int un = 0; un < UW; ++un) {
         const int unit = wave + 4 * un;
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int qi = q0[un] + 16 * j + c16;
+            if constexpr (DROPOUT) drop_row[un][j] = dropout_row_state(dropout_head_state(drop, item.x, h0 + hh_of[un]), qi);
             token[un][j] = -1;
             m_run[un][j] = -INFINITY;
             l_run[un][j] = 0.f;
@@ -312,16 +314,21 @@ __global__ __launch_bounds__(256, Cfg<DH>::kWaves) void attn_fused_fwd(
                 l_run[un][j] = fmaf(l_run[un][j], alpha, ps);
             }
             if constexpr (DROPOUT) {
+                // keys 4g .. 4g+3 of each 16-key half = two 2 x 2 blocks shared with lane c16 ^ 1 (same query pair):
+                // the even lane hashes the first, the odd lane the second, one DPP swap (dropout_pair_bits)
                 const int qi = q0[un] + 16 * j + c16;
+                const bool odd = c16 & 1;
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u) {
+                    const int kj = t * 32 + u * 16 + 4 * g;
+                    uint32_t bits[2];
+                    dropout_pair_bits(dropout_block_bits(drop_row[un][j], dropout_key_term(kj + (odd ? 2 : 0))), odd, &bits[0], &bits[1]);
 #pragma unroll
                     for (int r2 = 0; r2 < 2; ++r2) {
-                        const int kj = t * 32 + u * 16 + 4 * g + 2 * r2;
-                        const uint32_t bits = dropout_bits(drop, item.x, h0 + hh, qi, kj);
-                        if (dropout_dropped(drop, bits, qi, kj)) sc[u * 4 + 2 * r2] = 0.f;
-                        if (dropout_dropped(drop, bits, qi, kj + 1)) sc[u * 4 + 2 * r2 + 1] = 0.f;
+                        if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2)) sc[u * 4 + 2 * r2] = 0.f;
+                        if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2 + 1)) sc[u * 4 + 2 * r2 + 1] = 0.f;
                     }
+                }
             }
             bf16x8 p_hi, p_lo;
             split_frag(sc, &p_hi, &p_lo);

@@ -78,8 +78,11 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
     constexpr int NBQ = (DH + 15) / 16;  // 16-row d-blocks of a gradient
     static_assert(C::UW == 1, "one (tile, head) unit per wave");
-    __shared__ __attribute__((aligned(16))) char lds[C::NBUF * C::kTile + (MODE == 1 ? C::NBUF * 2 * HG * 32 * 4 : 0)];
+    __shared__ __attribute__((aligned(16))) char lds[C::NBUF * C::kTile + (MODE == 1 ? C::NBUF * (2 * HG * 32 + HG * 16) * 4 : 0)];
     float* ld_lds = reinterpret_cast<float*>(lds + C::NBUF * C::kTile);  // MODE 1: [buf][L | delta][head][32 tokens]
+    // MODE 1: dropout hash state of the streamed query pairs, [buf][head][16 pairs] (attn_dropout.hpp: the two-round part of
+    // the hash, once per query pair and tile instead of once per 2 x 2 block and lane)
+    uint32_t* rs_lds = reinterpret_cast<uint32_t*>(ld_lds + C::NBUF * 2 * HG * 32);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
             }
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int t_of) {
         char* base = lds + buf * C::kTile;
         if (st_which == 0) {  // image A: L2-normalise per head (x scale), split, row-major [token][head][DHS]
             char* dst = base + st_key * KRS;
@@ -209,6 +212,9 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     float* ld = ld_lds + buf * 2 * HG * 32;
                     ld[hh * 32 + st_key] = st_lse * kLog2e;
                     ld[HG * 32 + hh * 32 + st_key] = dsum;
+                    if (drop.threshold && (st_key & 1) == 0)
+                        rs_lds[(buf * HG + hh) * 16 + (st_key >> 1)] =
+                            dropout_row_state(dropout_head_state(drop, item.x, h0 + hh), t_of * 32 + st_key);
                 }
             }
         }
@@ -228,6 +234,14 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const bool active = st_tile < n_st_here;      // wave-uniform
     const bool two = n - s0 > 16;                 // the tile's second 16-token group exists (wave-uniform)
     bf16x8 a_hi[2][KS], a_lo[2][KS], b_hi[2][KS], b_lo[2][KS];  // stationary fragments: MODE 0 (Q~, dO), MODE 1 (K^, V)
+    // dropout, the stationary token's share of the hash: MODE 0 the query pair's state, MODE 1 the key pair's term
+    uint32_t drop_st[2] = {0u, 0u};
+    if (drop.threshold) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            drop_st[j] = MODE == 0 ? dropout_row_state(dropout_head_state(drop, item.x, h), s0 + 16 * j + c16)
+                                   : dropout_key_term(s0 + 16 * j + c16);
+    }
     float lq[2] = {0.f, 0.f}, dl[2] = {0.f, 0.f};                // MODE 0: log2-domain LSE and delta of the lane's queries
     int32_t token[2];
     {
@@ -379,13 +393,21 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 }
                 float dfac[4] = {1.f, 1.f, 1.f, 1.f};
                 if (drop.threshold) {  // the forward's dropout factors, regenerated (wave-uniform branch)
+                    // streamed tokens 4g .. 4g+3 of this 16-token half = two 2 x 2 blocks shared with lane c16 ^ 1 (same
+                    // stationary pair): the even lane hashes the first, the odd lane the second, one DPP swap
+                    const bool odd = c16 & 1;
+                    const int sm0 = t * 32 + u * 16 + 4 * g;
+                    uint32_t mine;
+                    if constexpr (MODE == 0) mine = dropout_block_bits(drop_st[j], dropout_key_term(sm0 + (odd ? 2 : 0)));
+                    else mine = dropout_block_bits(rs_lds[(buf * HG + hh) * 16 + u * 8 + 2 * g + (odd ? 1 : 0)], drop_st[j]);
+                    uint32_t bits[2];
+                    dropout_pair_bits(mine, odd, &bits[0], &bits[1]);
 #pragma unroll
                     for (int r2 = 0; r2 < 2; ++r2) {
-                        const int st_i = s0 + 16 * j + c16, sm_i = t * 32 + u * 16 + 4 * g + 2 * r2;
+                        const int st_i = s0 + 16 * j + c16, sm_i = sm0 + 2 * r2;
                         const int qi_ = MODE == 0 ? st_i : sm_i, kj_ = MODE == 0 ? sm_i : st_i;
-                        const uint32_t bits = dropout_bits(drop, item.x, h, qi_, kj_);
-                        dfac[2 * r2] = dropout_factor(drop, bits, qi_, kj_);
-                        dfac[2 * r2 + 1] = MODE == 0 ? dropout_factor(drop, bits, qi_, kj_ + 1) : dropout_factor(drop, bits, qi_ + 1, kj_);
+                        dfac[2 * r2] = dropout_factor(drop, bits[r2], qi_, kj_);
+                        dfac[2 * r2 + 1] = MODE == 0 ? dropout_factor(drop, bits[r2], qi_, kj_ + 1) : dropout_factor(drop, bits[r2], qi_ + 1, kj_);
                     }
                 }
 #pragma unroll
@@ -415,7 +437,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 
     // ---------------------------------------------------------------- main loop over the window's streamed tiles
     {
-        stage_store(0);
+        stage_store(0, 0);
         __syncthreads();
         for (int t = 0; t < n_t; ++t) {
             const bool more = t + 1 < n_t;
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
             }
             if (active) tile_step(t, buf);
             if (C::NBUF == 1) __syncthreads();
-            if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0);
+            if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0, t + 1);
             __syncthreads();
         }
     }

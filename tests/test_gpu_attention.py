@@ -100,24 +100,7 @@ def test_attention_forward_and_backward_vs_fp64(dev, windows, dh, tau):
 
 
 # ------------------------------------------------------------------------------------------ attention dropout
-def _mix(x):
-    x = x ^ (x >> np.uint32(15))
-    x = ((x & np.uint32(0xFFFFFF)) * np.uint32(0x9E3779) + (x >> np.uint32(24)) * np.uint32(0x85EBCA)).astype(np.uint32)
-    x = x ^ (x >> np.uint32(13))
-    x = ((x & np.uint32(0xFFFFFF)) * np.uint32(0xC2B2AF) + (x >> np.uint32(24)) * np.uint32(0x27D4EB)).astype(np.uint32)
-    return x ^ (x >> np.uint32(16))
-
-
-def dropout_factors(p, seed, window, head, n):
-    """csrc/attn_dropout.hpp restated with numpy uint32 arithmetic: [n, n] factors (0 or 1 / keep_prob) of one (window, head)."""
-    thr = min(max(int(p * 256.0 + 0.5), 1), 255)
-    with np.errstate(over="ignore"):
-        x0 = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(window) * np.uint32(0x9E3779B1))
-        x0 = _mix(np.array([x0 + np.uint32(head) * np.uint32(0x7F4A7C15) + np.uint32(seed >> 32)], dtype=np.uint32))[0]
-        qi, kj = np.meshgrid(np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32), indexing="ij")
-        bits = _mix(x0 ^ (((qi >> np.uint32(1)) << np.uint32(16)) | (kj >> np.uint32(1))))
-        byte = (bits >> (np.uint32(8) * ((qi & np.uint32(1)) * np.uint32(2) + (kj & np.uint32(1))))) & np.uint32(0xFF)
-    return np.where(byte < thr, 0.0, 256.0 / (256.0 - thr))
+from dropout_ref import dropout_factors  # noqa: E402  (csrc/attn_dropout.hpp restated with numpy)
 
 
 @pytest.mark.parametrize("dh", [6, 12, 24, 48])

@@ -4,6 +4,8 @@ import json
 import os
 
 import numpy as np
+
+import dropout_ref
 import pytest
 import torch
 
@@ -171,3 +173,23 @@ def test_spconv_checkpoint_layout_converter():
         assert "neither KRSC" in str(e)
     else:
         raise AssertionError("a weight in neither layout must be refused")
+
+
+def test_dropout_hash_statistics_on_host():
+    """The mask generator as a random source, on its host restatement (640-token windows, 6 seeds x 3 heads): drop rate of
+    the 26 / 256 threshold, lag-1 correlation of the drop indicator along keys, along queries and along the diagonal, and the
+    chi-square of the byte histogram, all within what an ideal generator gives (4 sigma)."""
+    n, thr = 640, 26
+    for seed in (1, 0x1234_5678_9ABC_DEF, 77 << 33):
+        for head in (0, 3, 7):
+            by = dropout_ref.dropout_bytes(seed, 5, head, n).astype(np.int64)
+            drop = (by < thr).astype(np.float64)
+            rate, cells = thr / 256.0, float(n * n)
+            assert abs(drop.mean() - rate) < 4.0 * (rate * (1 - rate) / cells) ** 0.5
+            d = drop - drop.mean()
+            var = float((d * d).mean())
+            for a, b in ((d[:, 1:], d[:, :-1]), (d[1:, :], d[:-1, :]), (d[1:, 1:], d[:-1, :-1]), (d[1:, :-1], d[:-1, 1:])):
+                assert abs(float((a * b).mean()) / var) < 4.0 / cells ** 0.5
+            h = np.bincount(by.reshape(-1), minlength=256).astype(np.float64)
+            chi2 = float(((h - cells / 256) ** 2 / (cells / 256)).sum())
+            assert abs(chi2 - 255.0) < 4.0 * (2 * 255.0) ** 0.5
