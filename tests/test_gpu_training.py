@@ -204,24 +204,44 @@ def test_eval_after_fused_optimizer_step_sees_the_new_weights():
         assert torch.equal(a, c), (fused, float((a - c).abs().max()))
 
 
-def test_every_parameter_gradient_matches_oracle_autograd():
-    """End-to-end BACKWARD parity: the gradient of a loss on all three heads w.r.t. every one of the 400+ parameters, GPU
+@pytest.mark.parametrize("variant", ["segformer", "spnet", "segformer_multi_sweep_fusion"])
+def test_every_parameter_gradient_matches_oracle_autograd(variant):
+    """End-to-end BACKWARD parity: the gradient of a loss on all three heads w.r.t. every parameter (400+ for Segformer), GPU
     path (the training-mode kernels: sparse-conv dgrad / wgrad, fused encoder layer, window-attention backward, LayerNorm /
-    BatchNorm backward, gather / scatter backward) against fp64 autograd through the CPU oracle.  Eval statistics (running
-    BatchNorm moments, no dropout / DropPath) make the two forward passes the same function; reference: the module tree of
-    seg3d/models/segmentors/segformer.py:94-146 and backbones/pointtransformer.py:181-219."""
+    BatchNorm backward, gather / scatter backward, kNN-indexed DeepFusion) against fp64 autograd through the CPU oracle.
+    Eval statistics (running BatchNorm moments, no dropout / DropPath) make the two forward passes the same function;
+    reference: the module trees of seg3d/models/segmentors/segformer.py:94-146 + backbones/pointtransformer.py:181-219,
+    segmentors/spnet.py:94-148 + backbones/spconv_unet.py:186-233 (BASELINE configs[3]) and the multi-sweep / image-fusion
+    switches of configs/waymo_multi_sweeps.yaml with layers/deep_fusion.py:26-45 (BASELINE configs[2])."""
     import numpy as np
     from oracle import index_ops, model as omodel, params
     from openseg3d_amd import batch as B, config, scene, segformer
     dev = torch.device("cuda:0")
     cfg = config.default_cfg()
+    multi = variant == "segformer_multi_sweep_fusion"
+    if variant == "spnet":
+        cfg.MODEL.SEGMENTOR = "spnet"
+    if multi:
+        cfg.DATASET.USE_MULTI_SWEEPS = cfg.DATASET.USE_IMAGE_FEATURE = True
     ds = config.DatasetSpec(cfg)
     model = segformer.build_segmentor(cfg, ds)
     params.fill_by_name(model, seed=0)
     model = model.to(dev).eval()
     pts = scene.make_small_scene(41, 3000, extent=7.0)
+    n_cur = pts.shape[0]
+    img = None
+    if multi:  # current sweep (time lag 0) + one jittered, shifted history sweep (lag 0.1), rows of waymo_dataset.py:156-202
+        rs = np.random.RandomState(5)
+        hist = pts[::2].copy()
+        hist[:, :3] += rs.normal(0.0, 0.02, size=(hist.shape[0], 3)).astype(np.float32)
+        hist[:, 0] += 0.4
+        hist[:, 3] = 0.1
+        pts = np.concatenate([pts, hist], axis=0)
+        img = scene.make_image_features(3, n_cur)
     # GPU: eval-mode forward with autograd on
-    b = B.make_batch([pts], ds.voxel_size, ds.point_cloud_range)
+    dev_pts = B.collate_points([pts], dev)
+    b = B.batch_from_resident(dev_pts, [n_cur], ds.voxel_size, ds.point_cloud_range,
+                              None if img is None else torch.from_numpy(img).to(dev))
     res = model(b)
     w_pt = torch.linspace(0.5, 1.5, 22, device=dev)
     loss = (res["point_out"] * w_pt).square().mean() + res["voxel_out"].square().mean() + res["aux_voxel_out"].square().mean()
@@ -230,15 +250,19 @@ def test_every_parameter_gradient_matches_oracle_autograd():
     coords, ids = index_ops.voxelize(pts, ds.voxel_size, ds.point_cloud_range)
     ob = {"points": torch.from_numpy(np.pad(pts, ((0, 0), (1, 0)))).double(),
           "voxel_coords": torch.from_numpy(np.pad(coords, ((0, 0), (1, 0)))).float(),
-          "point_voxel_ids": torch.from_numpy(ids).long(), "batch_size": 1}
+          "point_voxel_ids": torch.from_numpy(ids).long(), "batch_size": 1,
+          "point_id_offset": torch.tensor([float(n_cur)])}
+    if multi:
+        ob["point_image_features"] = torch.from_numpy(img).double()
     sd = model.state_dict()
     trainable = {k for k, _ in model.named_parameters()}
     p = {k: (v.detach().cpu().double().requires_grad_() if k in trainable else (v.cpu().double() if v.dtype.is_floating_point else v.cpu()))
          for k, v in sd.items()}
     ocfg = {"grid_size": index_ops.grid_size_of(ds.voxel_size, ds.point_cloud_range),
             "batching_info": [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO],
-            "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS}
-    ref = omodel.segformer_forward(ob, p, ocfg)
+            "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS,
+            "use_multi_sweeps": multi, "use_image_feature": multi}
+    ref = (omodel.spnet_forward if variant == "spnet" else omodel.segformer_forward)(ob, p, ocfg)
     assert float((res["point_out"].detach().cpu().double() - ref["point_out"].detach()).abs().max()) < 1e-3
     oloss = ((ref["point_out"] * w_pt.cpu().double()).square().mean() + ref["voxel_out"].square().mean()
              + ref["aux_voxel_out"].square().mean())
