@@ -62,9 +62,10 @@ __device__ __forceinline__ void through_normalise(const float* __restrict__ xrow
         for (int r = 0; r < 4; ++r) grad[b][r] = clamped ? grad[b][r] * rinv : (grad[b][r] - xr[b][r] * proj) * rinv;
 }
 
-// waves per SIMD the register allocator must leave room for (spill-free points; pass KV holds two accumulator sets)
+// waves per SIMD the register allocator must leave room for (spill-free points; pass KV holds two accumulator sets:
+// at dh 48 that is one wave per SIMD, accumulators in AGPRs)
 template <int DH, int MODE>
-constexpr int kBwdWaves = (DH <= 12 && MODE == 0) ? 3 : 2;
+constexpr int kBwdWaves = (DH <= 12 && MODE == 0) ? 3 : (DH == 48 && MODE == 1) ? 1 : 2;
 
 template <int DH, int MODE>
 __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
@@ -551,11 +552,13 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
 
 }  // namespace
 
-// dh 6 stays on the vector-ALU kernels (windows of ~15 voxels: 360 vs 475 us per layer on the headline scene), dh 48 on the
-// three-launch MFMA passes (pass KV would spill); measured per layer: dh 12 1540 -> 617 us, dh 24 780 -> 520 us
+// dh 6 stays on the vector-ALU kernels (windows of ~15 voxels: 360 vs 475 us per layer on the headline scene).  dh 48:
+// pass KV holds two 3-block accumulator sets + eight streamed fragments = 345 registers, i.e. ONE wave per SIMD (the
+// accumulators in AGPRs), and is still ahead of the three-launch MFMA passes with their prepared-operand round trip
+// (3 layers of the headline scene, dropout on: 1.58 -> 1.11 ms).  Measured per layer: dh 12 1540 -> 617 us, dh 24 780 -> 520 us
 bool attn_fused_bwd_supported(int heads, int dh) {
     static const bool all = getenv("SEG3D_ATTN_FUSED_BWD_ALL") != nullptr;  // A/B: also dh 6
-    return ((dh == 12 || (all && dh == 6)) && heads % 4 == 0) || dh == 24;
+    return ((dh == 12 || (all && dh == 6)) && heads % 4 == 0) || dh == 24 || dh == 48;
 }
 
 // floats of workspace the fused backward needs (one dtau partial per wave of pass Q)
@@ -581,7 +584,8 @@ int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ld
         SEG3D_FB(6);
         SEG3D_FB(12);
         SEG3D_FB(24);
-        default: return SEG3D_EINVAL;  // dh 48: pass KV would spill (two 3-block accumulator sets + eight streamed fragments)
+        SEG3D_FB(48);
+        default: return SEG3D_EINVAL;
     }
 #undef SEG3D_FB
 }
