@@ -167,6 +167,10 @@ def wrap_data_parallel(model, device, sync_bn=False):
     if sync_bn:
         model = convert_sync_bn(model)
     ids = [device.index] if device.type == "cuda" else None
+    # DDP's bucket hooks read .grad while the backward pass is still running: weight gradients launched on the side stream
+    # must be complete when their backward function returns (ops._WgradFork), not only at the end of the pass
+    from . import ops
+    ops.WGRAD_DEFER = False
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=False,
                                                      broadcast_buffers=False, gradient_as_bucket_view=True)
 

@@ -41,6 +41,123 @@ def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
 
 
+# Weight gradients on a second HIP stream.  In a backward function the input gradient (needed by the next function of the
+# chain) and the weight gradient (needed by the optimizer) are independent; the kernels of both leave matrix pipes, CUs
+# and memory pipes idle (tails of 459 workgroups on 512 slots, barrier-bound chunks), so the two co-run.  Protocol per
+# backward function: fork() = the side stream waits for everything enqueued so far on the current stream (the producers of
+# dy) and hands out its handle; the weight-gradient launches go there, everything else stays on the current stream;
+# join() = the current stream waits for the side stream, BEFORE the function returns -- autograd, DDP hooks and the
+# optimizer only ever see finished gradients.  Buffers handed to side-stream kernels are allocated on the current stream's
+# pool and kept alive until join(), after which the current stream's order covers them.  SEG3D_WGRAD_STREAM=0 turns it off.
+WGRAD_STREAM = os.environ.get("SEG3D_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """The process's second stream on that device (weight gradients in backward, the index plan in forward)."""
+    side = _SIDE_STREAMS.get(device.index)
+    if side is None:
+        side = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return side
+
+
+class _WgradFork:
+    def __init__(self, device):
+        self.on = WGRAD_STREAM and device.type == "cuda"
+        self.keep = []
+        self.used = False
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            self.side = side_stream(device)
+
+    def fork(self, *keep_alive):
+        """Stream handle for a weight-gradient launch whose operands are already enqueued on the current stream."""
+        if not self.on:
+            return _stream()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self.used = True
+        self.keep.extend(keep_alive)
+        return ctypes.c_void_p(self.side.cuda_stream)
+
+    def hold(self, *tensors):
+        self.keep.extend(tensors)
+
+    def join(self, *grads):
+        """grads: (parameter, gradient launched on the side stream) pairs -- decides whether the wait may be deferred to
+        the end of the backward pass (below); gradients that are None are ignored."""
+        if self.on and self.used:
+            if WGRAD_DEFER and _defer_join(self, [(w, gr) for w, gr in grads if gr is not None and w is not None]):
+                return
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+        self.keep = []
+
+
+# Deferred join (the default in single-process training): instead of waiting at the end of every backward function, the
+# current stream waits for the side stream ONCE, in a callback the autograd engine runs when the whole backward pass is
+# done -- the weight gradients then also overlap the memory-bound passes between the GEMMs (norm backward, activations,
+# gathers), not only their sibling input gradient: 50.1 -> 47.3 ms per step (per-function joins alone: 50.1 -> 49.9).
+# The gradient tensor is handed to autograd before its kernel has run, so deferral is taken only while nothing on the
+# current stream can touch it before that callback:
+#   * the parameter has no .grad yet (AccumulateGrad then stores the tensor, no kernel; zero_grad(set_to_none=True)),
+#     no tensor hooks, and appears for the first time in this pass (a second use would make the engine ADD the two
+#     gradients on the current stream -- the second appearance joins at once, which also covers the first);
+#   * no double backward (grad mode off inside the pass);
+#   * no DDP: its bucket hooks copy .grad during the pass -- dist.wrap_data_parallel sets WGRAD_DEFER = False.
+# Everything a pending launch touches (operands autograd frees when their node completes, workspaces, index tables) stays
+# referenced until the callback.  A callback is queued per deferral and is idempotent, so a pass that died in an exception
+# leaves nothing behind that the next pass does not clean up.  SEG3D_WGRAD_DEFER=0 turns deferral off.
+WGRAD_DEFER = os.environ.get("SEG3D_WGRAD_DEFER", "1") != "0"
+_DEFERRED = {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": []}
+
+
+def _final_join():
+    st = _DEFERRED
+    if st["side"] is None:
+        return
+    st["main"].wait_stream(st["side"])
+    # AccumulateGrad stores the incoming tensor itself when nobody else references it (the normal case: the gradient
+    # buffers below are aliases with their own TensorImpl, made for this check) and CLONES it otherwise -- a clone taken
+    # before the side stream had written the buffer.  Whatever the engine did, .grad holds the finished values from here on.
+    # (A parameter that appeared a second time in the pass was joined on the spot and summed by the engine: its .grad is a
+    # new tensor by right.)
+    for w, alias in st["fix"]:
+        g = w.grad
+        if g is not None and g.data_ptr() != alias.data_ptr() and w.data_ptr() not in st["twice"]:
+            g.copy_(alias.view_as(g))
+    st["keep"], st["main"], st["side"], st["seen"], st["twice"], st["fix"] = [], None, None, set(), set(), []
+
+
+def _defer_join(fk, grads):
+    st = _DEFERRED
+    if torch.is_grad_enabled() or not grads:
+        return False
+    bases = [w if w._base is None else w._base for w, _ in grads]
+    if any(base.data_ptr() in st["seen"] for base in bases):
+        st["twice"].update(base.data_ptr() for base in bases)  # second use: this call joins now, the engine sums
+        return False
+    for base in bases:
+        if not base.is_leaf or base.grad is not None or base._backward_hooks or not base.is_contiguous():
+            return False
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_final_join)
+    except RuntimeError:  # not inside a backward pass of the engine (a direct call): join now
+        return False
+    for base, (w, gr) in zip(bases, grads):
+        st["seen"].add(base.data_ptr())
+        if w is base:
+            st["fix"].append((base, gr.detach()))
+        else:
+            st["keep"].append(gr.detach())  # gradient of a view of the parameter: autograd scatters it, no .grad to check
+    st["main"], st["side"] = fk.main, fk.side
+    st["keep"].append(fk.keep)
+    fk.keep = []
+    return True
+
+
 def _i3(v):
     return _I3(*[int(x) for x in v])
 
@@ -421,17 +538,19 @@ class _SparseConvFn(torch.autograd.Function):
         dy = _f32c(dy)
         cout, cin = weight.shape[0], weight.shape[-1]
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = pack_weight(weight, ctx.t_flags)
-            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t)
-        if ctx.needs_input_grad[1]:
+        fk = _WgradFork(dy.device)
+        if ctx.needs_input_grad[1]:  # weight gradient first, on the side stream; the input gradient co-runs with it
             dw = torch.empty_like(weight, dtype=torch.float32)
             ws_bytes = _lib.query("seg3d_spconv_wgrad_workspace_bytes", dy.shape[0], cin, cout)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
             _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
-                      _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, _stream())
+                      _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, fk.fork(ws, dy, x, ctx.nbr))
+        if ctx.needs_input_grad[0]:
+            wt = pack_weight(weight, ctx.t_flags)
+            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
+        fk.join((weight, dw))
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -492,6 +611,7 @@ class _LinearFn(torch.autograd.Function):
         cout, cin = weight.shape
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.exact = bias is not None, exact
+        ctx.bias_param = bias  # (a reference for the deferred-join bookkeeping of the weight-gradient stream)
         if exact:  # exact-fp32 MFMA kernel (rocBLAS for odd shapes); only the weight gradient uses the split kernel
             if cin % 16 == 0 and cout % 16 == 0:
                 return _linear_apply_f32(x, _linear_pack_f32(weight, 0), None if bias is None else _f32c(bias), cin, cout)
@@ -504,6 +624,18 @@ class _LinearFn(torch.autograd.Function):
         dy = _f32c(dy)
         cout, cin = weight.shape
         dx = dw = db = None
+        fk = _WgradFork(dy.device)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:  # on the side stream, co-running with the input gradient below
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            if want_db:  # column sums of dy ride along with the weight-gradient pass
+                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+            ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
+            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws),
+                      ws_bytes, fk.fork(ws, dy, x))
+        elif want_db:
+            db = dy.sum(0)
         if ctx.needs_input_grad[0]:
             # ``exact`` protects the forward logits; the input gradient of an exact layer takes the split-bf16 kernel
             # like every other gradient of the step (16/3 the fp32-MFMA rate)
@@ -513,17 +645,7 @@ class _LinearFn(torch.autograd.Function):
                 dx = _linear_apply_f32(dy, _linear_pack_f32(weight, 1), None, cout, cin)
             else:
                 dx = dy @ weight
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            if want_db:  # column sums of dy ride along with the weight-gradient pass
-                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
-            ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
-            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws),
-                      ws_bytes, _stream())
-        elif want_db:
-            db = dy.sum(0)
+        fk.join((weight, dw), (ctx.bias_param, db))
         return dx, dw, db, None
 
 
@@ -1006,6 +1128,7 @@ class _AttnInProjFn(torch.autograd.Function):
         qk = _linear_apply(xp, _linear_pack(w_in[: 2 * c], 0), b_in[: 2 * c], c, 2 * c)
         v = _linear_apply(x, _linear_pack(w_in[2 * c:], 0), b_in[2 * c:], c, c)
         ctx.save_for_backward(x, xp, w_in)
+        ctx.b_in = b_in
         return qk, v
 
     @staticmethod
@@ -1015,6 +1138,15 @@ class _AttnInProjFn(torch.autograd.Function):
         m = x.shape[0]
         dqk, dv = _f32c(dqk), _f32c(dv)
         dx = dpos = dw = db = None
+        fk = _WgradFork(x.device)
+        if ctx.needs_input_grad[2]:  # both weight-gradient launches on the side stream, the input gradients co-run
+            dw = torch.empty((3 * c, c), dtype=torch.float32, device=x.device)
+            db = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
+            for src, dy, r0, rows in ((xp, dqk, 0, 2 * c), (x, dv, 2 * c, c)):
+                ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, c, rows)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+                _lib.call("seg3d_linear_wgrad", _ptr(src), _ptr(dy), m, c, rows, ctypes.c_void_p(dw.data_ptr() + 4 * r0 * c),
+                          ctypes.c_void_p(db.data_ptr() + 4 * r0), _ptr(ws), ws_bytes, fk.fork(ws, dy, src))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             # an enclosing layer function may hand over the residual path's gradient: it rides in the same epilogue
             extra = None if ctx.needs_input_grad[1] else getattr(ctx, "dx_addend", None)
@@ -1023,14 +1155,7 @@ class _AttnInProjFn(torch.autograd.Function):
                 dpos = d_xp
             if ctx.needs_input_grad[0]:
                 dx = _linear_apply(dv, _linear_pack(w_in[2 * c:], 1), None, c, c, addend=d_xp)  # both paths in one pass
-        if ctx.needs_input_grad[2]:
-            dw = torch.empty((3 * c, c), dtype=torch.float32, device=x.device)
-            db = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
-            for src, dy, r0, rows in ((xp, dqk, 0, 2 * c), (x, dv, 2 * c, c)):
-                ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, c, rows)
-                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-                _lib.call("seg3d_linear_wgrad", _ptr(src), _ptr(dy), m, c, rows, ctypes.c_void_p(dw.data_ptr() + 4 * r0 * c),
-                          ctypes.c_void_p(db.data_ptr() + 4 * r0), _ptr(ws), ws_bytes, _stream())
+        fk.join((w_in, dw), (ctx.b_in, db if ctx.needs_input_grad[3] else None))
         return dx, dpos, dw, (db if ctx.needs_input_grad[3] else None)
 
 
@@ -1055,13 +1180,15 @@ def window_attention(q, k, v, tau, tau_min, heads, wi):
     return _WindowAttnFn.apply(q, k, v, tau, tau_min, heads, wi)
 
 
-def _linear_wgrad(x, dy, cin, cout, want_db=True):
-    """(dW [cout, cin], db [cout] or None) of y = x W^T + b from the tall-skinny split-bf16 kernel (deterministic)."""
+def _linear_wgrad(x, dy, cin, cout, want_db=True, fork=None):
+    """(dW [cout, cin], db [cout] or None) of y = x W^T + b from the tall-skinny split-bf16 kernel (deterministic).
+    fork: a _WgradFork of the calling backward function -- the launch goes to the side stream, the caller joins."""
     dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
     db = torch.empty((cout,), dtype=torch.float32, device=dy.device) if want_db else None
     ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
     ws = _workspace(ws_bytes, dy.device)
-    _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream())
+    st = fork.fork(ws, x, dy) if fork is not None else _stream()
+    _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, st)
     return dw, db
 
 
@@ -1106,6 +1233,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
         ctx.parts = (c_in, c_at, c_n1, c_n2)
         ctx.save_for_backward(o, x1, h, g, w_out, w1, w2)
+        ctx.bias_params = (b_out, b1, b2)
         return x2
 
     @staticmethod
@@ -1115,18 +1243,23 @@ class _EncoderLayerFn(torch.autograd.Function):
         dx2 = _f32c(dx2)
         c, hid = x1.shape[1], w1.shape[0]
         # MLP branch: LN2 -> fc2 -> gelu' -> fc1, the residual gradient dx2 joins in fc1's epilogue
+        # the three weight gradients of this function go to the side stream as soon as their operands are enqueued and
+        # co-run with the chain below (the attention backward is the long pole); one join at the end
+        fk = _WgradFork(dx2.device)
         dm, _, dg2, dbe2, _, _ = _LayerNormResidualFn.backward(c_n2, dx2)
+        dw2, db2 = _linear_wgrad(g, dm, hid, c, fork=fk)
         dh = torch.ops.aten.gelu_backward(_linear_apply(dm, _linear_pack(w2, 1), None, c, hid), h)
-        dw2, db2 = _linear_wgrad(g, dm, hid, c)
+        dw1, db1 = _linear_wgrad(x1, dh, c, hid, fork=fk)
         d_x1 = _linear_apply(dh, _linear_pack(w1, 1), None, hid, c, addend=dx2)
-        dw1, db1 = _linear_wgrad(x1, dh, c, hid)
         # attention branch: LN1 -> out_proj -> attention -> in_proj, d_x1 joins in the in-projection's epilogue
         da, _, dg1, dbe1, _, _ = _LayerNormResidualFn.backward(c_n1, d_x1)
+        dw_out, db_out = _linear_wgrad(o, da, c, c, fork=fk)
         do = _linear_apply(da, _linear_pack(w_out, 1), None, c, c)
-        dw_out, db_out = _linear_wgrad(o, da, c, c)
         dqk, dv, dtau = _WindowAttnPackedFn.backward(c_at, do)[:3]
         c_in.dx_addend = d_x1
         dx, _, dw_in, db_in = _AttnInProjFn.backward(c_in, dqk, dv)
+        b_out, b1, b2 = ctx.bias_params
+        fk.join((w_out, dw_out), (w1, dw1), (w2, dw2), (b_out, db_out), (b1, db1), (b2, db2))
         ctx.parts = None
         return dx, None, dw_in, db_in, dtau, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, None
 

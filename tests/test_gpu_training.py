@@ -287,3 +287,55 @@ def test_every_parameter_gradient_matches_oracle_autograd(variant):
         tol = 5e-2 if k.endswith(".tau") else 2e-2
         assert rel <= tol or err <= 1e-7, (k, rel, err, scale, worst[:5])
     assert worst[len(worst) // 2][0] < 2e-3  # the median parameter is an order of magnitude closer
+
+
+def test_side_stream_weight_gradients_keep_autograd_semantics(monkeypatch):
+    """Weight gradients run on a second stream and, in the plain case, are only awaited at the end of the backward pass
+    (ops._WgradFork / _defer_join).  The cases where autograd touches the gradient earlier must give exactly what the
+    single-stream path gives (the kernels are deterministic, so: bit-identical): a weight and bias used twice in one
+    graph (the engine adds the two gradients), accumulation into an existing .grad, a tensor hook on the parameter,
+    torch.autograd.grad, create_graph, and a sparse-conv weight; plus fp64 autograd as the sanity bound."""
+    from openseg3d_amd import ops
+    assert ops.WGRAD_STREAM and ops.WGRAD_DEFER  # the defaults under test
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    m, c = 40000, 96
+    x = torch.randn(m, c, generator=gen).to(dev)
+    w0 = (torch.randn(c, c, generator=gen) / c ** 0.5).to(dev)
+    b0 = (torch.randn(c, generator=gen) * 0.1).to(dev)
+    g = torch.randn(m, c, generator=gen).to(dev)
+
+    def expr(lin, xx, w, b):  # the same weight and bias twice, a nonlinearity in between
+        return lin(torch.relu(lin(xx, w, b)), w, b)
+
+    def run():
+        out = {}
+        w, b = w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        expr(ops.linear, x, w, b).backward(g)
+        out["shared_w"], out["shared_b"] = w.grad.clone(), b.grad.clone()
+        expr(ops.linear, x, w, b).backward(g)  # accumulates into the existing .grad
+        out["acc_w"], out["acc_b"] = w.grad.clone(), b.grad.clone()
+        w3, seen = w0.clone().requires_grad_(), []
+        w3.register_hook(lambda gr: seen.append(gr.clone()))
+        ops.linear(x, w3, None).backward(g)
+        out["hook"], out["plain_w"] = seen[0], w3.grad.clone()
+        w4 = w0.clone().requires_grad_()
+        out["functional"] = torch.autograd.grad(ops.linear(x, w4, None), w4, g)[0].clone()
+        out["create_graph"] = torch.autograd.grad(ops.linear(x, w4, None), w4, g, create_graph=True)[0].detach().clone()
+        w5, b5 = w0.clone().requires_grad_(), b0.clone().requires_grad_()  # the plain deferred case, weight and bias
+        ops.linear(x, w5, b5).backward(g)
+        out["plain2_w"], out["plain2_b"] = w5.grad.clone(), b5.grad.clone()
+        torch.cuda.synchronize()
+        return out
+
+    got = run()
+    monkeypatch.setattr(ops, "WGRAD_STREAM", False)
+    want = run()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # sanity against fp64 autograd (ReLU masks that flip within the forward's rounding set the floor: torch's own fp32
+    # gradient differs from fp64 by 0.6 % of the largest entry on this expression)
+    w64, b64 = w0.double().cpu().requires_grad_(), b0.double().cpu().requires_grad_()
+    expr(torch.nn.functional.linear, x.double().cpu(), w64, b64).backward(g.double().cpu())
+    assert float((got["shared_w"].double().cpu() - w64.grad).abs().max()) <= 2e-2 * float(w64.grad.abs().max())
+    assert float((got["shared_b"].double().cpu() - b64.grad).abs().max()) <= 2e-2 * float(b64.grad.abs().max())
