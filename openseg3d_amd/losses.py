@@ -10,6 +10,9 @@ Same class names, constructor arguments and ``loss_name`` properties.  The confi
 the cross-entropy terms, one device sort for all classes of the Lovasz term.  Options the builder never sets (OHEM by
 keep_ratio, per-image / binary Lovasz) are composed from torch ops on the same device tensors.
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -126,9 +129,25 @@ def build_criterion(cfg, dataset):
     return losses
 
 
+AUX_OVERLAP = os.environ.get("SEG3D_AUX_OVERLAP", "1") != "0"
+
+
 def compute_loss(pred_result, data_dict, criterion, cfg):
     """tools/train.py:71-110: criterion on the point logits, the voxel logits and (x MODEL.AUX_LOSS_WEIGHT) the
     stride-8 auxiliary logits, whose ground truth is looked up by nearest fine voxel centre (ops.aux_voxel_labels)."""
+    # The auxiliary labels (a kNN lookup: no gradient, independent of the other two heads) are looked up on the second
+    # stream while this one computes the point and voxel losses; the streams meet in front of the auxiliary loss.
+    aux_gt = side = None
+    if "aux_voxel_out" in pred_result:
+        dev = pred_result["aux_voxel_out"].device
+        overlap = AUX_OVERLAP and dev.type == "cuda"
+        if overlap:
+            main, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
+            side.wait_stream(main)
+        with torch.no_grad(), torch.cuda.stream(side) if overlap else contextlib.nullcontext():
+            aux_gt = ops.aux_voxel_labels(pred_result["voxel_coords"], pred_result["aux_voxel_coords"],
+                                          data_dict["voxel_labels"], data_dict["batch_size"], cfg.DATASET.VOXEL_SIZE,
+                                          cfg.DATASET.POINT_CLOUD_RANGE)
     loss = 0
     for fn, w in criterion:
         loss = loss + fn(pred_result["point_out"], data_dict["point_labels"]) * w
@@ -136,11 +155,9 @@ def compute_loss(pred_result, data_dict, criterion, cfg):
         voxel_gt = data_dict["voxel_labels"]
         for fn, w in criterion:
             loss = loss + fn(pred_result["voxel_out"], voxel_gt) * w
-    if "aux_voxel_out" in pred_result:
-        with torch.no_grad():
-            aux_gt = ops.aux_voxel_labels(pred_result["voxel_coords"], pred_result["aux_voxel_coords"],
-                                          data_dict["voxel_labels"], data_dict["batch_size"], cfg.DATASET.VOXEL_SIZE,
-                                          cfg.DATASET.POINT_CLOUD_RANGE)
+    if aux_gt is not None:
+        if side is not None:
+            main.wait_stream(side)
         for fn, w in criterion:
             loss = loss + cfg.MODEL.AUX_LOSS_WEIGHT * fn(pred_result["aux_voxel_out"], aux_gt) * w
     return loss

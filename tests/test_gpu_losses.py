@@ -146,3 +146,12 @@ def test_compute_loss_on_model_outputs(dev):
         o, t = out.detach().cpu(), gt.cpu()
         want += w * (float(L.ohem_cross_entropy(o, t, cfg.MODEL.OHEM_KEEP_THRESH)) + float(L.lovasz_softmax(o, t)))
     assert abs(float(loss) - want) <= 1e-4 * abs(want), (float(loss), want)
+    # the auxiliary-label lookup runs on the second stream beside the other two heads' losses: same value, bit for bit,
+    # as with everything on one stream
+    with torch.no_grad():
+        both = []
+        for overlap in (True, False):
+            losses.AUX_OVERLAP = overlap
+            both.append(float(losses.compute_loss(res, b, crit, cfg)))
+        losses.AUX_OVERLAP = True
+    assert both[0] == both[1] == float(loss)
