@@ -659,6 +659,7 @@ class _LinearOddShapeFn(torch.autograd.Function):
         x = _f32c(x)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -667,8 +668,7 @@ class _LinearOddShapeFn(torch.autograd.Function):
         dy = _f32c(dy)
         cout, cin = weight.shape
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = dy @ weight
+        fk = _WgradFork(dy.device)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             pi, po = (-cin) % 4, (-cout) % 4
@@ -679,12 +679,20 @@ class _LinearOddShapeFn(torch.autograd.Function):
             ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin + pi, cout + po)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
             _lib.call("seg3d_linear_wgrad", _ptr(xp), _ptr(dyp), x.shape[0], cin + pi, cout + po, _ptr(dwp), _ptr(dbp),
-                      _ptr(ws), ws_bytes, _stream())
+                      _ptr(ws), ws_bytes, fk.fork(ws, xp, dyp))
             dw = dwp[:cout, :cin]
             if want_db:
                 db = dbp[:cout]
         elif want_db:
             db = dy.sum(0)
+        if ctx.needs_input_grad[0]:
+            dx = dy @ weight
+        # (padded shapes return VIEWS of the padded gradient: autograd copies those, so this function joins at once unless
+        # nothing was padded)
+        if (cin % 4) or (cout % 4):
+            fk.join()
+        else:
+            fk.join((weight, dw), (ctx.bias_param, db))
         return dx, dw, db
 
 
