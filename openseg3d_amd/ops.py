@@ -103,7 +103,7 @@ class _WgradFork:
 # The gradient tensor is handed to autograd before its kernel has run, so deferral is taken only while nothing on the
 # current stream can touch it before that callback:
 #   * the parameter has no .grad yet (AccumulateGrad then stores the tensor, no kernel; zero_grad(set_to_none=True)),
-#     no tensor hooks, and appears for the first time in this pass (a second use would make the engine ADD the two
+#     no tensor or post-accumulate hooks, and appears for the first time in this pass (a second use would make the engine ADD the two
 #     gradients on the current stream -- the second appearance joins at once, which also covers the first);
 #   * no double backward (grad mode off inside the pass);
 #   * no DDP: its bucket hooks copy .grad during the pass -- dist.wrap_data_parallel sets WGRAD_DEFER = False.
@@ -140,7 +140,8 @@ def _defer_join(fk, grads):
         st["twice"].update(base.data_ptr() for base in bases)  # second use: this call joins now, the engine sums
         return False
     for base in bases:
-        if not base.is_leaf or base.grad is not None or base._backward_hooks or not base.is_contiguous():
+        if (not base.is_leaf or base.grad is not None or base._backward_hooks or not base.is_contiguous()
+                or getattr(base, "_post_accumulate_grad_hooks", None)):
             return False
     try:
         torch.autograd.Variable._execution_engine.queue_callback(_final_join)
