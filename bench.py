@@ -65,6 +65,8 @@ def parse():
                          "auxiliary heads, tools/train.py:71-110); ce = plain cross-entropy on the three heads")
     ap.add_argument("--sync-bn", action="store_true", help="tools/train.py --sync_bn: SyncBatchNorm over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="build each step's batch and index plan at the start of the step "
+                    "instead of on the pipeline stream during the previous step")
     ap.add_argument("--cpu-points", type=int, default=-1,
                     help="points of the CPU-baseline / parity sample (0 = whole scene; default: whole scene, "
                          "150000 for dense2m and 30000 current-sweep rows for multi_sweeps so that the run stays within minutes)")
@@ -349,21 +351,66 @@ def main():
         voxel_labels.append(_ops.prepare_voxel_labels(b["point_voxel_ids"], labels[j], b["voxel_coords"].shape[0],
                                                       ignore_index=ds.ignore_index, cur_point_indices=cur).long())
 
-    def fwd_step(i):
-        j = i % len(resident)
+    # Input pipeline.  What depends on the raw points alone -- device voxelization, collation and the forward's index plan
+    # (site levels, rulebooks, window partitions; ~100 short dependent kernels and all of the forward's host read-backs) --
+    # is built for step i+1 on its own stream while step i computes: the reference overlaps the same work in its DataLoader
+    # workers (voxel_generator.py in waymo_dataset.py:__getitem__), here it stays on the GPU and inside the timed region
+    # (K steps time K voxelizations and K plans; the first timed step's was overlapped with the last warm-up step, the
+    # last timed step builds one that is never used).  --no-pipeline builds every batch at the start of its own step.
+    pipe_stream = _ops.side_stream(dev, 1) if (dev.type == "cuda" and not args.no_pipeline) else None
+    pending = {}
+
+    def build(j):
         b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j], cyl)
+        return model.prepare_batch(b) if pipe_stream is not None else b
+
+    def next_batch(i):
+        """Batch of step i; queues the build of step i+1's."""
+        main = torch.cuda.current_stream(dev) if pipe_stream is not None else None
+        item = pending.pop(i, None)
+        if item is None or len(item) != 2:  # nothing was built ahead (first step of a phase, --no-pipeline)
+            b = build(i % len(resident))
+        else:
+            b, done = item
+            main.wait_event(done)
+        if pipe_stream is not None:
+            # blocks the pipeline stream's allocator hands out again were freed by steps whose kernels are all in front of
+            # this point of the main stream: the build waits for it (not for step i itself)
+            mark = torch.cuda.Event()
+            mark.record(main)
+            pending.clear()
+            pending[i + 1] = (mark,)
+        return b
+
+    def prefetch(i):
+        """Called once step i is enqueued: step i+1's batch on the pipeline stream, beside step i's kernels."""
+        item = pending.get(i + 1)
+        if pipe_stream is None or item is None or len(item) != 1:
+            return
+        pipe_stream.wait_event(item[0])
+        with torch.cuda.stream(pipe_stream):
+            b = build((i + 1) % len(resident))
+            done = torch.cuda.Event()
+            done.record(pipe_stream)
+        pending[i + 1] = (b, done)
+
+    def fwd_step(i):
+        b = next_batch(i)
         with torch.no_grad():
-            return model(b)
+            res = model(b)
+        prefetch(i)
+        return res
 
     def train_step(i):
         j = i % len(resident)
-        b = B.batch_from_resident(resident[j], offsets[j], ds.voxel_size, ds.point_cloud_range, images[j], cyl)
+        b = next_batch(i)
         opt.zero_grad(set_to_none=True)
         res = net(b)
         data = {"point_labels": labels[j], "voxel_labels": voxel_labels[j], "batch_size": b["batch_size"]}
         loss = _losses.compute_loss(res, data, criterion, cfg)
         loss.backward()
         opt.step()
+        prefetch(i)
         return res
 
     def timed(step_fn):
@@ -408,7 +455,11 @@ def main():
                        "mode": args.mode, "segmentor": args.segmentor, "scenes_per_step_per_gpu": args.batch,
                        "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}",
                        "collective": (f"{dist.get_backend()} world {dist.get_world_size()}" + (", SyncBatchNorm" if args.sync_bn else ""))
-                       if distributed else None},
+                       if distributed else None,
+                       "streams": ("weight gradients + aux-label lookup on a second stream; "
+                                   + ("batch i+1's voxelization and index plan on a third stream beside step i (same K "
+                                      "voxelizations and plans inside the K timed steps)" if pipe_stream is not None
+                                      else "every batch built at the start of its own step (--no-pipeline)"))},
             "fwd_only": {"value": round(n_pts_f / dt_f, 1), "unit": "points/s",
                          "ms_per_step": round(dt_f / args.steps * 1e3, 3)},
             "roofline": roof,

@@ -53,11 +53,12 @@ WGRAD_STREAM = os.environ.get("SEG3D_WGRAD_STREAM", "1") != "0"
 _SIDE_STREAMS = {}
 
 
-def side_stream(device):
-    """The process's second stream on that device (weight gradients in backward, the index plan in forward)."""
-    side = _SIDE_STREAMS.get(device.index)
+def side_stream(device, which=0):
+    """The process's extra streams on that device: 0 = weight gradients in backward and the aux-label lookup of the
+    criterion; 1 = the input pipeline's (next batch's voxelization and index plan, bench.py)."""
+    side = _SIDE_STREAMS.get((device.index, which))
     if side is None:
-        side = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        side = _SIDE_STREAMS[(device.index, which)] = torch.cuda.Stream(device=device)
     return side
 
 

@@ -349,6 +349,14 @@ class Segformer(nn.Module):
                 nn.init.constant_(m.weight, 1.0)
                 nn.init.constant_(m.bias, 0)
 
+    def prepare_batch(self, batch_dict):
+        """The forward's index plan (site levels, rulebooks, window partitions: everything that depends on the voxel
+        coordinates only, and all of the forward's host read-backs), built ahead of time and carried by the batch -- an
+        input pipeline calls this for batch i+1 on its own stream while batch i trains (bench.py)."""
+        if "site_level" not in batch_dict:
+            self.point_transformer.prepare(batch_dict)
+        return batch_dict
+
     def forward(self, batch_dict):
         points = batch_dict["points"][:, 1:]
         ids = batch_dict["point_voxel_ids"]
@@ -357,7 +365,7 @@ class Segformer(nn.Module):
         seg = batch_dict.get("point_voxel_index")
         if seg is None:
             seg = ops.SegmentIndex(ids, n_voxels)
-        if PLAN_FIRST:
+        if PLAN_FIRST and "site_level" not in batch_dict:  # (a batch may arrive with its plan: prepare_batch below)
             # (Running the plan on a second stream under the point encoder changed nothing: 48.4 vs 48.5 ms.)
             self.point_transformer.prepare(batch_dict)
 

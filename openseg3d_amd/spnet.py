@@ -238,6 +238,12 @@ class SPNet(nn.Module):
                 nn.init.constant_(m.weight, 1.0)
                 nn.init.constant_(m.bias, 0)
 
+    def prepare_batch(self, batch_dict):
+        """The forward's index plan, built ahead of time and carried by the batch (segformer.Segformer.prepare_batch)."""
+        if "site_level" not in batch_dict:
+            self.voxel_encoder.prepare(batch_dict)
+        return batch_dict
+
     def forward(self, batch_dict):
         points = batch_dict["points"][:, 1:]
         ids = batch_dict["point_voxel_ids"]
@@ -245,7 +251,7 @@ class SPNet(nn.Module):
         seg = batch_dict.get("point_voxel_index")
         if seg is None:
             seg = ops.SegmentIndex(ids, n_voxels)
-        if segformer_mod.PLAN_FIRST:
+        if segformer_mod.PLAN_FIRST and "site_level" not in batch_dict:
             self.voxel_encoder.prepare(batch_dict)
         if self.use_multi_sweeps:
             cur_rows = torch.nonzero(points[:, 3] == 0).view(-1)  # spnet.py:97

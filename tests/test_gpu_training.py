@@ -339,3 +339,37 @@ def test_side_stream_weight_gradients_keep_autograd_semantics(monkeypatch):
     expr(torch.nn.functional.linear, x.double().cpu(), w64, b64).backward(g.double().cpu())
     assert float((got["shared_w"].double().cpu() - w64.grad).abs().max()) <= 2e-2 * float(w64.grad.abs().max())
     assert float((got["shared_b"].double().cpu() - b64.grad).abs().max()) <= 2e-2 * float(b64.grad.abs().max())
+
+
+def test_batch_prepared_on_the_pipeline_stream_gives_the_same_logits():
+    """bench.py's input pipeline: batch i+1 is voxelized, collated and planned (Segformer.prepare_batch) on its own stream
+    while batch i runs.  A batch built that way -- beside a forward in flight on the main stream, then handed over by an
+    event -- gives bit-identical logits to the same scene built and run on one stream; and a model run twice on a
+    prepared batch does not rebuild the plan."""
+    from openseg3d_amd import batch as B, config, ops, scene, segformer
+    dev = torch.device("cuda:0")
+    cfg = config.default_cfg()
+    ds = config.DatasetSpec(cfg)
+    torch.manual_seed(0)
+    model = segformer.build_segmentor(cfg, ds).to(dev).eval()
+    a = B.collate_points([scene.make_scene(5)[::3]], dev)
+    b = B.collate_points([scene.make_small_scene(9, 20000, extent=20.0)], dev)
+    na, nb = a.shape[0], b.shape[0]
+    with torch.no_grad():
+        plain = model(B.batch_from_resident(b, [nb], ds.voxel_size, ds.point_cloud_range))["point_out"].clone()
+        main, pipe = torch.cuda.current_stream(dev), ops.side_stream(dev, 1)
+        for _ in range(3):
+            mark = torch.cuda.Event()
+            mark.record(main)
+            res_a = model(B.batch_from_resident(a, [na], ds.voxel_size, ds.point_cloud_range))  # in flight on main
+            pipe.wait_event(mark)
+            with torch.cuda.stream(pipe):
+                bb = model.prepare_batch(B.batch_from_resident(b, [nb], ds.voxel_size, ds.point_cloud_range))
+                done = torch.cuda.Event()
+                done.record(pipe)
+            main.wait_event(done)
+            level = bb["site_level"]
+            out = model(bb)["point_out"]
+            assert bb["site_level"] is level  # the plan the batch carried was used, not rebuilt
+            assert torch.equal(out, plain)
+            del res_a
