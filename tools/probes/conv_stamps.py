@@ -51,12 +51,32 @@ def main():
               f"  | slowest wave {float(s[:, :, 6].max()):9.0f}")
         return y
 
+    orig_lin = ops._linear_apply
+
+    def hooked_lin(x, packed, bias, cin, cout, addend=None):
+        buf.zero_()
+        y = orig_lin(x, packed, bias, cin, cout, addend)
+        torch.cuda.synchronize()
+        s = buf.view(-1, 4, 8).double()
+        s = s[s[:, :, 6].sum(dim=1) > 0]
+        mean = s.mean(dim=(0, 1))
+        tot = float(mean[6])
+        names = ["issue", "mfma", "ldwait", "split", "commit", "barrier", "total", "prologue"]
+        loop = sum(float(mean[i]) for i in (0, 1, 2, 3, 4, 5))
+        print(f"LINEAR rows {x.shape[0]:7d} {cin:4d}->{cout:4d} wgs {s.shape[0]:4d} total {tot:9.0f} cyc  " +
+              "  ".join(f"{names[i]} {float(mean[i]) / tot * 100:4.1f}%" for i in (7, 0, 1, 2, 3, 4, 5)) +
+              f"  epilogue+rest {(tot - loop - float(mean[7])) / tot * 100:4.1f}%")
+        return y
+
     ops.conv_act = hooked
+    if "--linear" in sys.argv:
+        ops._linear_apply = hooked_lin
     try:
         with torch.no_grad():
             model(dict(b))
     finally:
         ops.conv_act = orig
+        ops._linear_apply = orig_lin
 
 
 if __name__ == "__main__":
