@@ -333,13 +333,6 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
         }
     }
 
-#ifdef SEG3D_CONV_STAMP
-    if (g_stamp_buf && lane == 0) {
-        unsigned long long* o = g_stamp_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
-        st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
-        for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
-    }
-#endif
     // D layout of v_mfma_f32_16x16x*: row = (lane>>4)*4 + r, col = lane & 15
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -369,6 +362,14 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                 }
             }
         }
+#ifdef SEG3D_CONV_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores are part of the wave's time
+    if (g_stamp_buf && lane == 0) {
+        unsigned long long* o = g_stamp_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 template <int NBT, int RB>
