@@ -466,6 +466,10 @@ def main():
             "conv_layers": [{k: l[k] for k in ("rows", "cin", "cout", "us", "bound", "frac")} for l in per_layer],
             "attention_roofline": ATTENTION_REPORT if args.segmentor == "segformer" else None,
         }
+        # fingerprint of the weights after the timed steps (fp64 sum of |w| over every parameter): the kernels are
+        # deterministic, so the streams, the deferred joins and the input pipeline must leave it unchanged to the last
+        # digit (SEG3D_WGRAD_STREAM=0 / --no-pipeline give the single-stream reference)
+        out["trained_weights_l1"] = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
         if baseline is not None:
             out["cpu_baseline"], out["parity"] = baseline
             # the trained module against a fresh module loaded from its state_dict: every cached operand (packed weights,

@@ -52,7 +52,8 @@ def test_training_step_reaches_every_parameter():
 def test_training_step_is_bit_reproducible(segmentor):
     """No kernel on the single-sweep training path accumulates with atomics (weight gradients, LayerNorm / BatchNorm sums,
     tau gradient, losses all reduce per-block partials in a fixed order): the same step from the same state yields the
-    same loss and the same gradients bit for bit, DropPath masks included once the generator is re-seeded."""
+    same loss and the same gradients bit for bit, DropPath masks included once the generator is re-seeded -- and whether
+    the weight gradients run on the second stream or not."""
     from openseg3d_amd import batch as B, config, losses, ops, scene, segformer
     dev = torch.device("cuda:0")
     cfg = config.default_cfg()
@@ -64,7 +65,10 @@ def test_training_step_is_bit_reproducible(segmentor):
     crit = losses.build_criterion(cfg, ds)
     samples = [scene.make_small_scene(17, 9000, extent=10.0), scene.make_small_scene(18, 5000, extent=6.0)]
     runs = []
-    for _ in range(2):
+    for rep in range(3):
+        # the third run puts every kernel on ONE stream: the second stream (weight gradients with their deferred join,
+        # aux-label lookup) must not change a bit either
+        ops.WGRAD_STREAM = losses.AUX_OVERLAP = rep < 2
         model.load_state_dict(state)
         model.zero_grad(set_to_none=True)
         torch.manual_seed(123)
@@ -77,9 +81,11 @@ def test_training_step_is_bit_reproducible(segmentor):
         loss = losses.compute_loss(res, b, crit, cfg)
         loss.backward()
         runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
-    assert torch.equal(runs[0][0], runs[1][0])
-    differing = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
-    assert not differing, differing[:8]
+    ops.WGRAD_STREAM = losses.AUX_OVERLAP = True
+    for other in (1, 2):
+        assert torch.equal(runs[0][0], runs[other][0])
+        differing = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[other][1][k])]
+        assert not differing, (other, differing[:8])
 
 
 def test_bench_prints_one_contract_line():
