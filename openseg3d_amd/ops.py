@@ -887,7 +887,7 @@ def _sync_batch_norm_act(x, bn, relu, res, group):
         shift = (bn.bias - mean * scale).contiguous()
         if bn.track_running_stats:
             bn._seg3d_stats_epoch = getattr(bn, "_seg3d_stats_epoch", 0) + 1
-            bn.num_batches_tracked += 1
+            _bump_batches_tracked(bn)
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1 - mom).add_(m2 / (total - 1).clamp_(min=1.0), alpha=mom)
@@ -912,7 +912,7 @@ def narrow_batch_norm(x, bn):
         ws = _workspace(ws_bytes, x.device)
         _lib.call("seg3d_batchnorm_stats", _ptr(xp), m, cp, float(bn.eps), _ptr(w), _ptr(b), 0.0, None, None, _ptr(stats),
                   _ptr(ws), ws_bytes, _stream())
-        bn.num_batches_tracked += 1
+        _bump_batches_tracked(bn)
         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         d = stats[0, :c] / m  # mean of (x - x[0]); biased variance from the shifted sums, as the kernel forms it
         var = (stats[1, :c] / m - d * d).clamp_(min=0.0)
@@ -920,6 +920,36 @@ def narrow_batch_norm(x, bn):
         bn.running_var.mul_(1 - mom).add_(var, alpha=mom * (m / max(m - 1, 1)))
     y = _BatchNormActFn.apply(xp, None, w, b, stats[2], stats[3], stats[4], stats[5], False)
     return y[:, :c]
+
+
+# BatchNorm's num_batches_tracked += 1 is a kernel launch per layer and forward (28 on the training step's critical path).
+# Inside a segmentor's forward the counters are collected and bumped by ONE foreach launch at the end; with momentum=None
+# (cumulative average: the value is needed at once) and outside that scope the increment happens on the spot.
+_BN_COUNTERS = None
+
+
+class deferred_bn_counters:
+    def __enter__(self):
+        global _BN_COUNTERS
+        self.outer = _BN_COUNTERS
+        if _BN_COUNTERS is None:
+            _BN_COUNTERS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_COUNTERS
+        if self.outer is None:
+            pending, _BN_COUNTERS = _BN_COUNTERS, None
+            if pending:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
+def _bump_batches_tracked(bn):
+    if _BN_COUNTERS is not None and bn.momentum is not None:
+        _BN_COUNTERS.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
 
 
 def bn_eval_affine(bn):
@@ -963,7 +993,7 @@ def batch_norm_act(x, bn, relu=True, res=None):
             if track:
                 # the kernel updates the running buffers through raw pointers: tell the eval-affine cache
                 bn._seg3d_stats_epoch = getattr(bn, "_seg3d_stats_epoch", 0) + 1
-                bn.num_batches_tracked += 1
+                _bump_batches_tracked(bn)
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", m, c)
             ws = _workspace(ws_bytes, x.device)

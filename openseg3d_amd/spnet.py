@@ -245,6 +245,10 @@ class SPNet(nn.Module):
         return batch_dict
 
     def forward(self, batch_dict):
+        with ops.deferred_bn_counters():  # one launch for all BatchNorm step counters
+            return self._forward(batch_dict)
+
+    def _forward(self, batch_dict):
         points = batch_dict["points"][:, 1:]
         ids = batch_dict["point_voxel_ids"]
         n_voxels = batch_dict["voxel_coords"].shape[0]

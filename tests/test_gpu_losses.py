@@ -135,6 +135,9 @@ def test_compute_loss_on_model_outputs(dev):
     crit = losses.build_criterion(cfg, ds)
     assert [type(f).__name__ for f, _ in crit] == ["OHEMCrossEntropyLoss", "LovaszLoss"]
     res = model(b)
+    # BatchNorm step counters: bumped by one batched launch at the end of the forward (ops.deferred_bn_counters)
+    counters = [int(m.num_batches_tracked) for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert counters and set(counters) == {1}
     loss = losses.compute_loss(res, b, crit, cfg)
     loss.backward()
     assert not [k for k, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
