@@ -379,3 +379,20 @@ def test_batch_prepared_on_the_pipeline_stream_gives_the_same_logits():
             assert bb["site_level"] is level  # the plan the batch carried was used, not rebuilt
             assert torch.equal(out, plain)
             del res_a
+
+
+def test_bench_streams_and_pipeline_train_the_same_weights():
+    """bench.py's default run (weight gradients + aux-label lookup on a second stream with the deferred join, next batch's
+    voxelization and index plan on a third) and the same steps with everything on ONE stream (`--no-pipeline`,
+    SEG3D_WGRAD_STREAM=0, SEG3D_AUX_OVERLAP=0) end with the same weights to the last digit of an fp64 fingerprint: the
+    kernels are deterministic, so any hand-over that came too early or too late would show here."""
+    def run(extra, env):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--scenes", "2",
+                              "--mode", "fwdbwd", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900,
+                             cwd=ROOT, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    a = run([], {})
+    b = run(["--no-pipeline"], {"SEG3D_WGRAD_STREAM": "0", "SEG3D_AUX_OVERLAP": "0"})
+    assert "third stream" in a["config"]["streams"] and "--no-pipeline" in b["config"]["streams"]
+    assert a["trained_weights_l1"] == b["trained_weights_l1"] and a["trained_weights_l1"] > 0
