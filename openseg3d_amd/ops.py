@@ -532,6 +532,7 @@ class _SparseConvFn(torch.autograd.Function):
         y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout, order)
         ctx.save_for_backward(x, weight)
         ctx.nbr, ctx.nbr_t, ctx.t_flags, ctx.has_bias, ctx.order_t = nbr, nbr_t, t_flags, bias is not None, order_t
+        ctx.bias_param = bias
         return y
 
     @staticmethod
@@ -551,8 +552,13 @@ class _SparseConvFn(torch.autograd.Function):
             wt = pack_weight(weight, ctx.t_flags)
             dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0)
-        fk.join((weight, dw))
+            if fk.on:  # a parameter gradient like dw: column sums of dy on the side stream
+                fk.fork(dy)
+                with torch.cuda.stream(fk.side):
+                    db = dy.sum(0)
+            else:
+                db = dy.sum(0)
+        fk.join((weight, dw), (ctx.bias_param, db))
         return dx, dw, db, None, None, None, None, None, None
 
 
