@@ -58,7 +58,10 @@ def side_stream(device, which=0):
     criterion; 1 = the input pipeline's (next batch's voxelization and index plan, bench.py)."""
     side = _SIDE_STREAMS.get((device.index, which))
     if side is None:
-        side = _SIDE_STREAMS[(device.index, which)] = torch.cuda.Stream(device=device)
+        # SEG3D_SIDE_PRIORITY: HIP stream priority of the extra streams (the main chain is the critical path; a lower
+        # priority lets its workgroups go first where both streams have some ready)
+        prio = int(os.environ.get("SEG3D_SIDE_PRIORITY", "0"))
+        side = _SIDE_STREAMS[(device.index, which)] = torch.cuda.Stream(device=device, priority=prio)
     return side
 
 
