@@ -7,7 +7,6 @@ Scenes are independent in forward and backward: the only data-path exchange is t
 import os
 import socket
 import subprocess
-import sys
 import time
 
 import torch
