@@ -480,6 +480,10 @@ def main():
         # deterministic, so the streams, the deferred joins and the input pipeline must leave it unchanged to the last
         # digit (SEG3D_WGRAD_STREAM=0 / --no-pipeline give the single-stream reference)
         out["trained_weights_l1"] = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        # the attention temperature after the timed steps: below ~0.036 the kernels leave the fixed-maximum softmax
+        taus = [float(p.detach()) for n, p in model.named_parameters() if n.endswith(".tau")]
+        if taus and out["attention_roofline"] is not None:
+            out["attention_roofline"]["tau_range_after_steps"] = [round(min(taus), 4), round(max(taus), 4)]
         if baseline is not None:
             out["cpu_baseline"], out["parity"] = baseline
             # the trained module against a fresh module loaded from its state_dict: every cached operand (packed weights,

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--workload", default="one_sweep")
     ap.add_argument("--drop", type=float, default=0.0)
     ap.add_argument("--stages", default="0,1,2,3")
+    ap.add_argument("--tau", type=float, default=1.0, help="value of the learnable temperature (tau_min = 0.01 clamps below)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = config.default_cfg()
@@ -37,7 +38,7 @@ def main():
             part = swformer.SparseWindowPartitionLayer(info[stage], cfg.MODEL.WINDOW_SHAPE, [float(g) / 2 ** stage for g in ds.grid_size])
             plan = part.plan(level.coords, 1, c)
             m = level.coords.shape[0]
-            tau = torch.ones((1, 1, 1), device=dev)
+            tau = torch.full((1, 1, 1), args.tau, device=dev)
             for shift in (0, 1):
                 wi = plan.index[shift]
                 qk = torch.randn(m, 2 * c, device=dev, requires_grad=args.bwd)
