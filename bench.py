@@ -111,7 +111,9 @@ def conv_roofline(model, batch, dev):
     ops._conv_apply = timed
     ops.conv_act = timed_act
     ops.window_attention_packed = timed_attn
-    passes = 3  # the figure is an average over 3 instrumented forwards (60 launches): one pass alone moves by +-5 %
+    # per layer the MEDIAN over 5 instrumented forwards: an event bracket also contains whatever the host does between
+    # the two records while the GPU idles (an allocator miss -> hipMalloc), and one such stall must not enter the figure
+    passes = 5
     try:
         with torch.no_grad():
             for _ in range(passes):
@@ -124,11 +126,14 @@ def conv_roofline(model, batch, dev):
     # window attention (all kernels of one layer's attention core): algorithmic FLOPs 4*C*sum_w n_w^2
     sq_cache, a_flop, a_ms = {}, 0.0, 0.0
     by_width = {}
-    for wi, c, e0, e1 in attn_records:
+    n_attn = len(attn_records) // passes
+    for li in range(n_attn):
+        wi, c, _, _ = attn_records[li]
         if id(wi) not in sq_cache:
             cnt = wi.win_count[: wi.n_windows].double()
             sq_cache[id(wi)] = float((cnt * cnt).sum().item())
-        fl, ms = 4.0 * c * sq_cache[id(wi)] / passes, e0.elapsed_time(e1) / passes
+        fl = 4.0 * c * sq_cache[id(wi)]
+        ms = float(np.median([attn_records[li + k * n_attn][2].elapsed_time(attn_records[li + k * n_attn][3]) for k in range(passes)]))
         a_flop += fl
         a_ms += ms
         w = by_width.setdefault(c, [0.0, 0.0, 0])
@@ -143,8 +148,8 @@ def conv_roofline(model, batch, dev):
         "achieved": round(attn_tf, 2), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(attn_tf / MFMA_BF16_TFLOPS, 5),
         "note": "algorithmic 4*C*sum(n_w^2) FLOPs per layer / HIP-event time; executed MFMA FLOPs are higher (split-bf16 "
                 "products, padding of heads and of windows to tiles)",
-        "layers": len(attn_records) // passes, "gflop_per_forward": round(a_flop / 1e9, 2), "ms_per_forward": round(a_ms, 3),
-        "by_width": {str(c): {"layers": w[2] // passes, "us_per_layer": round(w[1] * 1e3 / max(w[2] // passes, 1), 1),
+        "layers": n_attn, "gflop_per_forward": round(a_flop / 1e9, 2), "ms_per_forward": round(a_ms, 3),
+        "by_width": {str(c): {"layers": w[2], "us_per_layer": round(w[1] * 1e3 / max(w[2], 1), 1),
                               "TFLOPs": round(w[0] / w[1] / 1e9, 1) if w[1] > 0 else 0.0} for c, w in sorted(by_width.items())}}
     pairs_cache, tot_bytes, tot_ms = {}, 0.0, 0.0
     per_layer = []
@@ -156,7 +161,7 @@ def conv_roofline(model, batch, dev):
             pairs_cache[key] = int((nbr >= 0).sum().item())
         p = pairs_cache[key]
         algo = p * (cin + cout) * 4 + 27 * cin * cout * 4 + p * 8
-        ms = sum(records[li + k * n_layers][3].elapsed_time(records[li + k * n_layers][4]) for k in range(passes)) / passes
+        ms = float(np.median([records[li + k * n_layers][3].elapsed_time(records[li + k * n_layers][4]) for k in range(passes)]))
         tot_bytes += algo
         tot_ms += ms
         m_out = int(nbr.shape[1])
@@ -184,7 +189,7 @@ def conv_roofline(model, batch, dev):
         if abs(p.get("algorithmic_bytes_per_launch", 0) - tot_bytes / n) <= 0.01 * tot_bytes / n:
             traffic, traffic_src = p["traffic_bytes_per_launch"], f"quoted from profiles/{name} (rocprofv3 --pmc, same workload)"
             break
-    return {"bound": "hbm", "kernel": f"spconv_split_kernel (all {n_layers} sparse-conv launches of one forward, mean of {passes} forwards)",
+    return {"bound": "hbm", "kernel": f"spconv_split_kernel (all {n_layers} sparse-conv launches of one forward, per-layer median of {passes} forwards)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "launches": n_layers,
             "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
@@ -413,13 +418,18 @@ def main():
         prefetch(i)
         return res
 
-    def timed(step_fn):
+    local_sec = {}
+
+    def timed(step_fn, tag):
         for i in range(args.warmup):
             step_fn(i)
         D.job_barrier(dev)
         t0 = time.perf_counter()
         for i in range(args.steps):
             step_fn(args.warmup + i)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        local_sec[tag] = time.perf_counter() - t0  # this rank alone (the job's time below adds the wait for the slowest)
         D.job_barrier(dev)
         sec = time.perf_counter() - t0
         pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
@@ -432,17 +442,41 @@ def main():
         hi = torch.cuda.Stream(device=dev, priority=-1)
         hi.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(hi)
+    weights_l1 = None
+    nosync_ms = None
     if train:
         net.train()
-        dt, n_pts = timed(train_step)
+        dt, n_pts = timed(train_step, "train")
+        # fingerprint of the weights after the timed steps (fp64 sum of |w| over every parameter): the kernels are
+        # deterministic, so the streams, the deferred joins and the input pipeline must leave it unchanged to the last
+        # digit (SEG3D_WGRAD_STREAM=0 / --no-pipeline give the single-stream reference); under DDP every rank must hold
+        # the same value
+        weights_l1 = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        if distributed and world > 1:
+            # what the gradient exchange costs on the critical path: the same steps with DDP's all-reduce switched off
+            # (no_sync), after the fingerprint -- the ranks' weights diverge from here on, only eval timing follows
+            k = min(args.steps, 5)
+            D.job_barrier(dev)
+            t0 = time.perf_counter()
+            with net.no_sync():
+                for i in range(k):
+                    train_step(args.warmup + args.steps + i)
+            D.job_barrier(dev)
+            nosync_ms = (time.perf_counter() - t0) / k * 1e3
     net.eval()
-    dt_f, n_pts_f = timed(fwd_step)  # forward-only eval (BASELINE configs[1] as literally worded)
-    if hi is not None:
-        torch.cuda.default_stream(dev).wait_stream(hi)
-        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    dt_f, n_pts_f = timed(fwd_step, "fwd")  # forward-only eval (BASELINE configs[1] as literally worded)
+    # (the instrumented passes below stay on the same stream: its allocator pool is warm, so no hipMalloc lands inside
+    # an event bracket -- the narrow-head layers of the dense scene once read 11 ms instead of 1.1 ms that way)
     if not train:
         dt, n_pts = dt_f, n_pts_f
 
+    rank_report = None
+    if distributed:  # one record per rank: a scaling problem shows as one slow rank or as a large exchange share
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu",
+                "ms_per_step": round(local_sec.get("train", local_sec["fwd"]) / args.steps * 1e3, 3),
+                "fwd_ms_per_step": round(local_sec["fwd"] / args.steps * 1e3, 3), "trained_weights_l1": weights_l1}
+        rank_report = [None] * world
+        dist.all_gather_object(rank_report, mine)
     out = None
     if rank == 0:
         model.eval()
@@ -476,10 +510,16 @@ def main():
             "conv_layers": [{k: l[k] for k in ("rows", "cin", "cout", "us", "bound", "frac")} for l in per_layer],
             "attention_roofline": ATTENTION_REPORT if args.segmentor == "segformer" else None,
         }
-        # fingerprint of the weights after the timed steps (fp64 sum of |w| over every parameter): the kernels are
-        # deterministic, so the streams, the deferred joins and the input pipeline must leave it unchanged to the last
-        # digit (SEG3D_WGRAD_STREAM=0 / --no-pipeline give the single-stream reference)
-        out["trained_weights_l1"] = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        out["trained_weights_l1"] = weights_l1 if weights_l1 is not None else \
+            float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        if rank_report is not None:
+            out["ranks"] = rank_report
+            if nosync_ms is not None:
+                out["allreduce"] = {"ms_per_step_without_exchange": round(nosync_ms, 3),
+                                    "exposed_ms_per_step": round(dt / args.steps * 1e3 - nosync_ms, 3),
+                                    "gradient_bytes": int(sum(p.numel() for p in model.parameters()) * 4),
+                                    "note": "DDP buckets over " + dist.get_backend() + "; exposed = timed step minus the "
+                                            "same step under no_sync()"}
         # the attention temperature after the timed steps: below ~0.036 the kernels leave the fixed-maximum softmax
         taus = [float(p.detach()) for n, p in model.named_parameters() if n.endswith(".tau")]
         if taus and out["attention_roofline"] is not None:
@@ -498,6 +538,9 @@ def main():
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
             json.dump(per_layer, f, indent=1)
         print(json.dumps(out), flush=True)
+    if hi is not None:
+        torch.cuda.default_stream(dev).wait_stream(hi)
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,6 +14,9 @@ image (requirements.txt:4, version unpinned), so neither layout -- nor spconv's 
 cross-correlation, as torch's conv3d), nor its tap orientation for SparseInverseConv3d -- can be verified offline.  What
 is tested (tests/test_host_logic.py) is the shape recognition and that the permutation round-trips.
 """
+import os
+import warnings
+
 import torch
 
 
@@ -41,7 +44,15 @@ def convert_spconv_state_dict(state_dict, model):
 def load_reference_checkpoint(model, path_or_dict, strict=True):
     """``model.load_state_dict`` for a checkpoint written by the reference's tools/train.py (key 'model') or a bare
     state_dict, with the sparse-conv weights converted to this package's layout first."""
-    ckpt = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, (str, bytes)) else path_or_dict
+    is_path = isinstance(path_or_dict, (str, bytes, os.PathLike))
+    ckpt = torch.load(os.fspath(path_or_dict), map_location="cpu") if is_path else path_or_dict
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt and not torch.is_tensor(ckpt["model"]) else ckpt
     sd = {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}  # DDP-wrapped saves
-    return model.load_state_dict(convert_spconv_state_dict(sd, model), strict=strict)
+    converted = convert_spconv_state_dict(sd, model)
+    if any(torch.is_tensor(v) and v.dim() == 5 for v in converted.values()):
+        # say so at load time rather than only in the module docstring: wrong logits from a real checkpoint would be silent
+        warnings.warn("openseg3d_amd.checkpoint: sparse-conv weights are ASSUMED to be stored KRSC [Cout,kz,ky,kx,Cin] or "
+                      "RSCK [kz,ky,kx,Cin,Cout] with kz-major offsets (spconv 2.x); this converter has never been checked "
+                      "against a file written by spconv itself -- verify a few logits against the source framework",
+                      stacklevel=2)
+    return model.load_state_dict(converted, strict=strict)

@@ -1021,10 +1021,30 @@ size_t bwd_bytes(int n_tiles, int heads, int dh) {
 
 extern "C" {
 
+// which kernels the backward takes for this head geometry: 0 fused (two flash-style passes), 1 vector-ALU (dh 6),
+// 2 legacy three-launch MFMA passes with prepared operands
+static int attn_bwd_path(int heads, int dh) {
+    static const bool fused_bwd_off = getenv("SEG3D_ATTN_FUSED_BWD") && atoi(getenv("SEG3D_ATTN_FUSED_BWD")) == 0;  // A/B
+    if (!fused_bwd_off && attn_use_fused(heads, dh) && attn_fused_bwd_supported(heads, dh)) return 0;
+    // narrow heads: the vector-ALU kernels win at dh 6 (364 vs 1552 us per layer on the headline scene), the MFMA passes
+    // at dh 12 (1210 vs 1547 us)
+    if (attn_use_small(heads, dh) && dh < 12) return 1;
+    return 2;
+}
+
+// Bytes for the path seg3d_window_attn_fwd / _bwd will actually take with these arguments: the fused kernels keep
+// nothing in HBM but one tau-gradient partial per wave; only the legacy kernels (SEG3D_ATTN_FUSED=0, head counts the fused
+// kernels do not take) stage prepared operands -- gigabytes on a 2 M-point scene, which the callers used to allocate per
+// call whatever the path.
 size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t n_tiles, int32_t heads, int32_t dh) {
     if (m < 0 || heads <= 0 || n_tiles < 0) return 0;
-    const size_t fwd = attn_mfma_workspace_bytes(n_tiles, heads, dh);
-    const size_t bwd = bwd_bytes(n_tiles, heads, dh);
+    size_t fwd = 0, bwd = 0;
+    if (!attn_use_fused(heads, dh) && !attn_use_small(heads, dh)) fwd = attn_mfma_workspace_bytes(n_tiles, heads, dh);
+    switch (attn_bwd_path(heads, dh)) {
+        case 0: bwd = attn_fused_bwd_workspace_bytes(n_tiles, n_tiles, heads, dh); break;  // chunks <= tiles
+        case 1: bwd = (size_t)n_tiles * sizeof(float); break;
+        default: bwd = bwd_bytes(n_tiles, heads, dh);
+    }
     return (fwd > bwd ? fwd : bwd) + 256;
 }
 
@@ -1049,16 +1069,14 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
         ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
           reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15))
         return SEG3D_EINVAL;  // rows are gathered / stored in 16-B pieces
-    static const bool fused_bwd_off = getenv("SEG3D_ATTN_FUSED_BWD") && atoi(getenv("SEG3D_ATTN_FUSED_BWD")) == 0;  // A/B
-    if (!fused_bwd_off && attn_use_fused(heads, dh) && attn_fused_bwd_supported(heads, dh)) {
+    const int path = attn_bwd_path(heads, dh);
+    if (path == 0) {
         if (workspace_bytes < attn_fused_bwd_workspace_bytes(n_tiles, n_qgroups, heads, dh)) return SEG3D_EWORKSPACE;
         return attn_fused_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
                                      qg_item, n_qgroups, heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau,
                                      workspace, drop, as_stream(stream));
     }
-    // narrow heads: the vector-ALU kernels win at dh 6 (364 vs 1552 us per layer on the headline scene), the MFMA passes
-    // at dh 12 (1210 vs 1547 us)
-    if (attn_use_small(heads, dh) && dh < 12) {
+    if (path == 1) {
         if (workspace_bytes < (size_t)n_tiles * sizeof(float)) return SEG3D_EWORKSPACE;
         return attn_small_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
                                      heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, workspace, drop,

@@ -26,6 +26,27 @@
 
 #include "attn_fused.hpp"
 
+#ifdef SEG3D_ATTN_STAMP
+// Diagnostic build only (tools/probes/attn_stamps.py): per-wave s_memtime sums of the forward's phases.
+__device__ unsigned long long* g_attn_stamp_buf = nullptr;
+extern "C" int seg3d_debug_attn_stamps(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : 2;
+}
+#define ASTAMP(i)                                                    \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        st_acc[i] += t_ - st_last;                                   \
+        st_last = t_;                                                \
+    } while (0)
+#define AKEEP(x) asm volatile("" ::"v"(x))
+#else
+#define ASTAMP(i) do {} while (0)
+#define AKEEP(x) do {} while (0)
+#endif
+
 namespace {
 
 using namespace attn;
@@ -44,8 +65,15 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
+#ifdef SEG3D_ATTN_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
     const int2 item = items[blockIdx.x];
     const int n = win_count[item.x], start = win_start[item.x];
+    AKEEP(n); AKEEP(start);
+    ASTAMP(0);  // item record + window geometry (two dependent round trips)
     const int n_kt = (n + 31) >> 5;
     const int h0 = blockIdx.y * HG;
     const float qscale = kLog2e / fmaxf(tau[0], tau_min);
@@ -167,7 +195,12 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
     // the rows) overlap those of the queries instead of following them -- these workgroups live for a few microseconds,
     // most of it memory latency.
     int32_t tok_next = n_kt > 1 ? load_tok(1) : 0;
-    stage_load(load_tok(0));
+    {
+        const int32_t tok0 = load_tok(0);
+        AKEEP(tok0);
+        ASTAMP(1);  // token indices of the first key tile
+        stage_load(tok0);
+    }
 
     // ---------------------------------------------------------------- this wave's (tile, head) units
     const int n_qt_here = min(QT, n_kt - item.y * QT);  // query tiles of the item that exist
@@ -377,8 +410,11 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
 
     // ---------------------------------------------------------------- main loop over the window's key tiles
     auto run = [&](auto fixed_tag) {
+        ASTAMP(2);  // query prologue (token, row gather, normalise, split)
         stage_store(0);
+        ASTAMP(3);  // wait for the first key tile's rows + convert + LDS store
         __syncthreads();
+        ASTAMP(4);  // barriers
         for (int t = 0; t < n_kt; ++t) {
             const bool more = t + 1 < n_kt;
             const int buf = C::NBUF == 2 ? (t & 1) : 0;
@@ -389,9 +425,13 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
 #pragma unroll
             for (int un = 0; un < UW; ++un)
                 if (active[un]) tile_step(fixed_tag, un, t, lds + buf * C::kTile);
+            ASTAMP(5);  // tile compute (LDS fragment reads, MFMAs, softmax)
             if (C::NBUF == 1) __syncthreads();  // everyone is done with the only buffer
+            ASTAMP(4);
             if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0);
+            ASTAMP(3);
             __syncthreads();
+            ASTAMP(4);
         }
     };
     if (fixed_max) run(std::true_type{});
@@ -399,6 +439,15 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
 #pragma unroll
     for (int un = 0; un < UW; ++un)
         if (active[un]) finish(fixed_max, un);
+#ifdef SEG3D_ATTN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(6);  // epilogue (normalise, stores)
+    if (g_attn_stamp_buf && lane == 0) {
+        unsigned long long* o = g_attn_stamp_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        st_acc[7] = st_last - st_begin;
+        for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 template <int DH>

@@ -92,6 +92,7 @@ class _WgradFork:
         """grads: (parameter, gradient launched on the side stream) pairs -- decides whether the wait may be deferred to
         the end of the backward pass (below); gradients that are None are ignored."""
         if self.on and self.used:
+            _drop_stale_deferred()
             if WGRAD_DEFER and _defer_join(self, [(w, gr) for w, gr in grads if gr is not None and w is not None]):
                 return
             ev = torch.cuda.Event()
@@ -106,16 +107,39 @@ class _WgradFork:
 # gathers), not only their sibling input gradient: 50.1 -> 47.3 ms per step (per-function joins alone: 50.1 -> 49.9).
 # The gradient tensor is handed to autograd before its kernel has run, so deferral is taken only while nothing on the
 # current stream can touch it before that callback:
+#   * NO process group exists in this process (torch.distributed not initialised): DistributedDataParallel, FSDP, comm
+#     hooks and optimizer-in-backward all hang their work on the AccumulateGrad node (C++ post hooks a Python check
+#     cannot see) and copy or reduce the gradient during the pass -- safe by construction, whoever wraps the model;
 #   * the parameter has no .grad yet (AccumulateGrad then stores the tensor, no kernel; zero_grad(set_to_none=True)),
 #     no tensor or post-accumulate hooks, and appears for the first time in this pass (a second use would make the engine ADD the two
 #     gradients on the current stream -- the second appearance joins at once, which also covers the first);
 #   * no double backward (grad mode off inside the pass);
-#   * no DDP: its bucket hooks copy .grad during the pass -- dist.wrap_data_parallel sets WGRAD_DEFER = False.
+#   * the start-up probe (probe_deferred_join, run once per process before the first training backward) found the
+#     deferred result bit-identical to the joined one: the protocol leans on autograd internals (queue_callback, the
+#     identity of the tensor AccumulateGrad stores), and a torch release that changes them must turn deferral off, not
+#     train on unfinished buffers.
 # Everything a pending launch touches (operands autograd frees when their node completes, workspaces, index tables) stays
-# referenced until the callback.  A callback is queued per deferral and is idempotent, so a pass that died in an exception
-# leaves nothing behind that the next pass does not clean up.  SEG3D_WGRAD_DEFER=0 turns deferral off.
+# referenced until the callback.  The bookkeeping is stamped with the engine's graph-task id: a pass that died in an
+# exception (the engine then skips its final callbacks) leaves state that the first deferral of the NEXT pass drops after
+# joining the streams.  SEG3D_WGRAD_DEFER=0 turns deferral off.
 WGRAD_DEFER = os.environ.get("SEG3D_WGRAD_DEFER", "1") != "0"
-_DEFERRED = {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": []}
+_DEFERRED = {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": [], "task": None}
+_DEFER_PROBE = {"done": False, "ok": None}
+
+
+def _graph_task_id():
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return fn() if fn is not None else -1
+
+
+def _reset_deferred():
+    st = _DEFERRED
+    st["keep"], st["main"], st["side"], st["seen"], st["twice"], st["fix"], st["task"] = [], None, None, set(), set(), [], None
+
+
+def _process_group_exists():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def _final_join():
@@ -132,13 +156,24 @@ def _final_join():
         g = w.grad
         if g is not None and g.data_ptr() != alias.data_ptr() and w.data_ptr() not in st["twice"]:
             g.copy_(alias.view_as(g))
-    st["keep"], st["main"], st["side"], st["seen"], st["twice"], st["fix"] = [], None, None, set(), set(), []
+    _reset_deferred()
+
+
+def _drop_stale_deferred():
+    """State left behind by a pass that raised before the engine ran its callbacks (another graph task's): whatever it
+    launched is joined now and its aliases are dropped -- they belong to gradients nobody will read."""
+    st = _DEFERRED
+    if st["side"] is not None and st["task"] != _graph_task_id():
+        st["main"].wait_stream(st["side"])
+        _reset_deferred()
 
 
 def _defer_join(fk, grads):
     st = _DEFERRED
-    if torch.is_grad_enabled() or not grads:
+    _drop_stale_deferred()
+    if torch.is_grad_enabled() or not grads or _DEFER_PROBE["ok"] is False or _process_group_exists():
         return False
+    task = _graph_task_id()
     bases = [w if w._base is None else w._base for w, _ in grads]
     if any(base.data_ptr() in st["seen"] for base in bases):
         st["twice"].update(base.data_ptr() for base in bases)  # second use: this call joins now, the engine sums
@@ -157,10 +192,70 @@ def _defer_join(fk, grads):
             st["fix"].append((base, gr.detach()))
         else:
             st["keep"].append(gr.detach())  # gradient of a view of the parameter: autograd scatters it, no .grad to check
-    st["main"], st["side"] = fk.main, fk.side
+    st["main"], st["side"], st["task"] = fk.main, fk.side, task
     st["keep"].append(fk.keep)
     fk.keep = []
     return True
+
+
+def probe_deferred_join(device):
+    """Start-up self-test of the deferred join (once per process; the segmentors call it before their first training
+    forward).  Two Linear layers are differentiated twice from the same inputs: with every weight gradient joined at the end
+    of its backward function, and deferred -- with the side stream held busy by a long kernel so that a gradient read before
+    the final join cannot be complete, and the freed gradient buffers poisoned so that it cannot be right by accident.
+    Bit-identical results keep deferral on; anything else (a torch release whose engine no longer runs the callback, or
+    clones the gradient where it used to keep it) turns it off for the process with a warning.  Returns the verdict."""
+    global WGRAD_DEFER
+    pr = _DEFER_PROBE
+    if pr["done"] or not (WGRAD_STREAM and WGRAD_DEFER) or device.type != "cuda":
+        return pr["ok"]
+    pr["done"] = True
+    if _process_group_exists():  # never deferred in such a process anyway
+        return None
+    try:
+        with torch.cuda.device(device), torch.enable_grad():
+            gen = torch.Generator().manual_seed(11)
+            m, c = 16384, 64
+            x = torch.randn(m, c, generator=gen).to(device)
+            g = torch.randn(m, c, generator=gen).to(device)
+            w0 = [(torch.randn(c, c, generator=gen) / 8.0).to(device) for _ in range(2)]
+            b0 = [(torch.randn(c, generator=gen) * 0.1).to(device) for _ in range(2)]
+
+            def grads(defer):
+                global WGRAD_DEFER
+                ws = [t.clone().requires_grad_() for t in w0]
+                bs = [t.clone().requires_grad_() for t in b0]
+                WGRAD_DEFER = defer
+                try:
+                    if defer:
+                        side = side_stream(device)
+                        side.wait_stream(torch.cuda.current_stream(device))
+                        with torch.cuda.stream(side):  # ~1 ms of work in front of the weight gradients
+                            big = torch.empty((2048, 2048), device=device).normal_()
+                            for _ in range(8):
+                                big = big @ big * 1e-3
+                        junk = [torch.full((c, c), float("nan"), device=device) for _ in range(4)]
+                        del junk  # the blocks the gradient buffers are most likely to be carved from
+                    y = linear(torch.relu(linear(x, ws[0], bs[0])), ws[1], bs[1])
+                    y.backward(g)
+                finally:
+                    WGRAD_DEFER = True
+                return [t.grad for t in ws + bs]
+            want = [t.clone() for t in grads(False)]
+            got = grads(True)
+            torch.cuda.synchronize(device)
+            ok = all(a is not None and torch.equal(a, b) for a, b in zip(got, want))
+    except Exception as e:  # noqa: BLE001 -- any failure of the probe means: do not defer
+        ok = False
+        import warnings
+        warnings.warn(f"openseg3d_amd: deferred weight-gradient join probe raised {type(e).__name__}: {e}")
+    pr["ok"] = bool(ok)
+    if not ok:
+        WGRAD_DEFER = False
+        import warnings
+        warnings.warn("openseg3d_amd: the deferred weight-gradient join did not reproduce the joined gradients on this "
+                      "torch build; falling back to per-function joins (SEG3D_WGRAD_DEFER=0)")
+    return pr["ok"]
 
 
 def _i3(v):

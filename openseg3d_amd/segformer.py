@@ -358,6 +358,8 @@ class Segformer(nn.Module):
         return batch_dict
 
     def forward(self, batch_dict):
+        if self.training and torch.is_grad_enabled():
+            ops.probe_deferred_join(batch_dict["points"].device)  # once per process: self-test of the deferred join
         with ops.deferred_bn_counters():  # one launch for all BatchNorm step counters
             return self._forward(batch_dict)
 

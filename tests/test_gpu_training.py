@@ -396,3 +396,82 @@ def test_bench_streams_and_pipeline_train_the_same_weights():
     b = run(["--no-pipeline"], {"SEG3D_WGRAD_STREAM": "0", "SEG3D_AUX_OVERLAP": "0"})
     assert "third stream" in a["config"]["streams"] and "--no-pipeline" in b["config"]["streams"]
     assert a["trained_weights_l1"] == b["trained_weights_l1"] and a["trained_weights_l1"] > 0
+
+
+def test_deferred_join_probe_passes_and_catches_a_broken_engine(monkeypatch):
+    """ops.probe_deferred_join is the start-up self-test behind SEG3D_WGRAD_DEFER: on this torch build the deferred and the
+    joined gradients are bit-identical (True); with the engine's final callback disabled -- what a torch release that
+    changed `queue_callback` would look like -- the probe must notice (the side stream is kept busy and the buffers are
+    poisoned) and switch deferral off for the process."""
+    from openseg3d_amd import ops
+    dev = torch.device("cuda:0")
+    monkeypatch.setattr(ops, "WGRAD_DEFER", True)
+    monkeypatch.setitem(ops._DEFER_PROBE, "done", False)
+    monkeypatch.setitem(ops._DEFER_PROBE, "ok", None)
+    assert ops.probe_deferred_join(dev) is True and ops.WGRAD_DEFER
+    assert ops.probe_deferred_join(dev) is True  # cached: one probe per process
+    monkeypatch.setitem(ops._DEFER_PROBE, "done", False)
+    monkeypatch.setitem(ops._DEFER_PROBE, "ok", None)
+    engine = torch.autograd.Variable._execution_engine
+    monkeypatch.setattr(ops, "_final_join", lambda: None)  # the callback runs but no longer joins the streams
+    with pytest.warns(UserWarning, match="deferred weight-gradient join"):
+        assert ops.probe_deferred_join(dev) is False
+    assert ops.WGRAD_DEFER is False
+    del engine
+    torch.cuda.synchronize()
+    ops._reset_deferred()
+
+
+def _ddp_ranks(world, backend, env=None):
+    from openseg3d_amd import dist as D
+    drv = ("import sys\nsys.path.insert(0, %r)\nfrom openseg3d_amd import dist as D\n"
+           "sys.exit(D.launch_local_ranks([sys.executable, %r], %d))\n" % (ROOT, os.path.join(ROOT, "tests", "_ddp_rank.py"), world))
+    out = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, SEG3D_DDP_BACKEND=backend, **(env or {})))
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [json.loads(l[len("DDPRANK "):]) for l in out.stdout.splitlines() if l.startswith("DDPRANK ")]
+    assert len(recs) == world
+    return sorted(recs, key=lambda r: r["rank"])
+
+
+def _check_ddp_mean(recs, singles):
+    import numpy as np
+    assert all(r["n_nonfinite"] == 0 and not r["deferred_in_this_process"] for r in recs)
+    a, b = recs
+    assert a["probe"] == b["probe"] and a["total"] == b["total"]  # every rank holds the same reduced gradient
+    want = (np.asarray(singles[0]["probe"]) + np.asarray(singles[1]["probe"])) / 2
+    got = np.asarray(a["probe"])
+    assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30)
+
+
+def test_plain_ddp_wrapper_gets_finished_gradients():
+    """A model wrapped in torch's DistributedDataParallel DIRECTLY (not via dist.wrap_data_parallel): DDP's bucket hooks
+    read the gradients during the backward pass, so nothing may be deferred in a process that has a process group --
+    safe by construction (ops._process_group_exists).  Two gloo ranks share the card; every rank must end with the mean
+    of the two single-rank gradients, and the weight-gradient stream on / off must not change a bit."""
+    both = _ddp_ranks(2, "gloo")
+    off = _ddp_ranks(2, "gloo", {"SEG3D_WGRAD_STREAM": "0"})
+    assert [r["probe"] for r in both] == [r["probe"] for r in off] and [r["total"] for r in both] == [r["total"] for r in off]
+    singles = [_ddp_ranks(1, "gloo", {"SEG3D_DDP_ONLY_SCENE": str(r), "SEG3D_BENCH_DIST": "1"})[0] for r in range(2)]
+    _check_ddp_mean(both, singles)
+
+
+def test_two_gpus_rccl_all_reduce():
+    """First contact with a second GPU (skipped on a one-GPU box): the same two-rank step over `nccl` (= RCCL over xGMI),
+    one card per rank -- equal reduced gradients on both ranks, equal to the mean of the two single-rank gradients -- and
+    `bench.py --gpus 2` end to end (fresh children via launch_local_ranks, never an exec): one contract line,
+    `config.collective == "nccl world 2"`, per-rank step times reported, both ranks trained the same weights."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    both = _ddp_ranks(2, "nccl")
+    assert all(r["backend"] == "nccl" for r in both)
+    singles = [_ddp_ranks(1, "gloo", {"SEG3D_DDP_ONLY_SCENE": str(r), "SEG3D_BENCH_DIST": "1"})[0] for r in range(2)]
+    _check_ddp_mean(both, singles)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["collective"] == "nccl world 2"
+    ranks = line["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["ms_per_step"] > 0 for r in ranks)
+    assert ranks[0]["trained_weights_l1"] == ranks[1]["trained_weights_l1"] > 0

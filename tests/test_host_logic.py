@@ -158,8 +158,23 @@ def test_spconv_checkpoint_layout_converter():
     n_conv = sum(v.dim() == 5 for v in sd.values())
     assert n_conv == 20  # 14 submanifold + 3 strided + 3 inverse convs (pointtransformer.py:132-179)
     other = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
-    res = checkpoint.load_reference_checkpoint(other, {"model": rsck, "epoch": 3})
+    import pathlib
+    import tempfile
+    import warnings
+    with warnings.catch_warnings(record=True) as seen:  # the assumed spconv layout is announced at load time
+        warnings.simplefilter("always")
+        res = checkpoint.load_reference_checkpoint(other, {"model": rsck, "epoch": 3})
+    assert any("ASSUMED" in str(w.message) for w in seen)
     assert not res.missing_keys and not res.unexpected_keys
+    with tempfile.TemporaryDirectory() as d:  # a pathlib.Path is a path, not a state dict
+        f = pathlib.Path(d) / "epoch_3.pth"
+        torch.save({"model": rsck, "epoch": 3}, f)
+        third = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res3 = checkpoint.load_reference_checkpoint(third, f)
+        assert not res3.missing_keys and not res3.unexpected_keys
+        assert all(torch.equal(v, sd[k]) for k, v in third.state_dict().items())
     for k, v in other.state_dict().items():
         assert torch.equal(v, sd[k]), k
     same = checkpoint.convert_spconv_state_dict(sd, model)  # already KRSC: untouched
@@ -193,3 +208,80 @@ def test_dropout_hash_statistics_on_host():
             h = np.bincount(by.reshape(-1), minlength=256).astype(np.float64)
             chi2 = float(((h - cells / 256) ** 2 / (cells / 256)).sum())
             assert abs(chi2 - 255.0) < 4.0 * (2 * 255.0) ** 0.5
+
+
+def test_deferred_join_bookkeeping_is_safe_by_construction(monkeypatch):
+    """ops._defer_join on the CPU autograd engine with stand-in streams (no kernel runs): the join is deferred to the
+    engine's final callback in the plain case; NEVER when a process group exists in the process (DDP / FSDP / comm hooks
+    hang their work on the AccumulateGrad node where no Python check sees it); and the state a pass leaves behind when it
+    raises mid-backward (the engine then skips its callbacks) is joined and dropped by the next pass instead of pinning
+    tensors or being compared with the next pass's gradients."""
+    from types import SimpleNamespace
+    from openseg3d_amd import ops
+
+    class FakeStream:
+        def __init__(self):
+            self.waits = 0
+
+        def wait_stream(self, other):
+            self.waits += 1
+
+    log = []
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            return x * w.sum()
+
+        @staticmethod
+        def backward(ctx, dy):
+            gr = torch.full_like(ctx.w, 2.0)
+            fk = SimpleNamespace(main=FakeStream(), side=FakeStream(), keep=[gr])
+            log.append((ops._defer_join(fk, [(ctx.w, gr)]), fk))
+            return dy * ctx.w.sum(), gr
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, dy):
+            raise RuntimeError("boom")
+
+    monkeypatch.setattr(ops, "WGRAD_DEFER", True)
+    monkeypatch.setitem(ops._DEFER_PROBE, "ok", True)
+    x = torch.ones(3, requires_grad=True)
+    w = torch.ones(4, requires_grad=True)
+    Fn.apply(x, w).sum().backward()
+    deferred, fk = log.pop()
+    assert deferred and fk.main.waits == 1 and ops._DEFERRED["side"] is None and not ops._DEFERRED["seen"]
+    assert torch.equal(w.grad, torch.full((4,), 2.0))
+
+    # a process group exists -> joined at the end of the backward function, whoever wrapped the model
+    monkeypatch.setattr(ops, "_process_group_exists", lambda: True)
+    w.grad = None
+    Fn.apply(x, w).sum().backward()
+    assert log.pop()[0] is False and ops._DEFERRED["side"] is None
+    monkeypatch.setattr(ops, "_process_group_exists", lambda: False)
+
+    # the probe said no -> never deferred
+    monkeypatch.setitem(ops._DEFER_PROBE, "ok", False)
+    w.grad = None
+    Fn.apply(x, w).sum().backward()
+    assert log.pop()[0] is False
+    monkeypatch.setitem(ops._DEFER_PROBE, "ok", True)
+
+    # a pass that dies after a deferral leaves state; the next pass joins and drops it before deferring again
+    w.grad = None
+    with pytest.raises(RuntimeError, match="boom"):
+        Fn.apply(Boom.apply(x), w).sum().backward()
+    deferred, dead = log.pop()
+    assert deferred and ops._DEFERRED["side"] is dead.side and dead.main.waits == 0  # callback skipped
+    w2 = torch.ones(4, requires_grad=True)
+    Fn.apply(x, w2).sum().backward()
+    deferred, fk = log.pop()
+    assert deferred and dead.main.waits == 1 and fk.main.waits == 1
+    assert ops._DEFERRED["side"] is None and not ops._DEFERRED["fix"] and not ops._DEFERRED["keep"]
+    assert torch.equal(w2.grad, torch.full((4,), 2.0))
