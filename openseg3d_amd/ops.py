@@ -240,8 +240,10 @@ def probe_deferred_join(device):
                     y.backward(g)
                 finally:
                     WGRAD_DEFER = True
-                return [t.grad for t in ws + bs]
-            want = [t.clone() for t in grads(False)]
+                # what the optimizer would read: copies enqueued on the CURRENT stream right behind the pass, no device
+                # synchronisation in between -- a missing join shows as the poison (or as stale bytes) in these copies
+                return [None if t.grad is None else t.grad.clone() for t in ws + bs]
+            want = grads(False)
             got = grads(True)
             torch.cuda.synchronize(device)
             ok = all(a is not None and torch.equal(a, b) for a, b in zip(got, want))
