@@ -4,7 +4,18 @@
 //
 // What the earlier forward did in two launches (attn_prepare_fwd: gather + L2-normalise + bf16 hi/lo split + transposed
 // copies through HBM; attn_core_fwd_lds: the MFMA core) happens here inside the core's own staging step:
-//   * a workgroup (4 waves) owns the queries of one work item and walks the window's 32-key tiles.  Per key tile all 256
+//   * PERSISTENT workgroups (4 waves): the grid is one round of resident workgroups, each walks its share of the work
+//     items (item = blockIdx.x + j * gridDim.x) in a software-pipelined loop.  In-kernel stamps of the one-item-per-
+//     workgroup form (tools/probes/attn_stamps.py) showed where a workgroup's life went: 10-18 % fetching its item record
+//     and window geometry, 25-40 % in the query prologue (token index -> scattered 8-B row gathers -> normalise), 8-21 %
+//     waiting for key rows, and only 19-28 % multiplying -- four dependent memory round trips per item with nothing to
+//     overlap them.  Here the item descriptors of a workgroup are resolved ONCE into LDS, the token indices of item j + 1
+//     are fetched while item j's first key tile is multiplied, and its query / first-key rows are requested before item
+//     j's epilogue: the chain of item j + 1 runs under the arithmetic of item j;
+//   * the queries take the same road as the keys: all 256 threads gather whole 16-B pieces of the query rows (4 threads
+//     per row), normalise, scale by log2e / tau, split and park them in an LDS image; a wave pulls its B fragments out
+//     of it with ds_read_b128 (the scattered 8-B fragment-shaped global loads of the earlier prologue are gone);
+//   * a workgroup owns the queries of one work item and walks the window's 32-key tiles.  Per key tile all 256
 //     threads gather the raw fp32 k / v rows (4 threads per key), normalise k, split everything to bf16 hi + lo and park
 //     the tile in LDS ROW-major ([key][head][channel]) -- K is read back as MFMA A fragments with ds_read_b128, V^T
 //     fragments come out of the same row-major image through ds_read_b64_tr_b16 (the hardware transpose read), so nothing
@@ -22,6 +33,7 @@
 // Arithmetic: split-bf16 products (hi*hi + hi*lo + lo*hi), fp32 accumulate, as everywhere else on this path.
 // Training: attention-probability dropout (cosine_msa.py:172-174) is applied to P inside the same loop from a counter-
 // based hash of (seed, window, head, query, key); the backward regenerates the same mask (attn_dropout.hpp).
+#include <cstdlib>
 #include <type_traits>
 
 #include "attn_fused.hpp"
@@ -52,16 +64,42 @@ namespace {
 using namespace attn;
 using namespace attn_fused;
 
+
+// LDS the persistent forward needs beyond the key / value tiles: the query image (two planes) + the tokens of its rows
+// + the workgroup's resolved item descriptors (a ring of kDescRing)
+constexpr int kDescRing = 256;
+#ifndef SEG3D_ATTN_DH6_WAVES
+#define SEG3D_ATTN_DH6_WAVES 4
+#endif
+template <int DH>
+struct FwdGeo {
+    using C = Cfg<DH>;
+    static constexpr int QROWS = C::QT * 32;                       // stationary (query) rows of an item
+    static constexpr int QRS = C::HG * C::DHS * 2 + (C::kNarrow ? 16 : (DH == 24 ? 16 : 16));  // bytes per row per plane
+    static constexpr int kQPlane = QROWS * QRS;
+    static constexpr int QP = C::kNarrow ? 1 : 2;                  // staging passes over the query rows (64 rows x 4 threads)
+    static constexpr int NBUF = C::NBUF;  // (double-buffering the narrow configurations too lost: 77 -> 87 us at dh 6)
+    static constexpr int kBytes = NBUF * C::kTile + 2 * kQPlane + QROWS * 4 + kDescRing * 16;
+    // waves per SIMD = resident workgroups per CU the register allocator leaves room for (spill-free points)
+    static constexpr int waves(bool dropout) { return DH == 48 ? 2 : (DH == 6 && !dropout ? SEG3D_ATTN_DH6_WAVES : 3); }
+};
+
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>::kWaves)) void attn_fused_fwd(
+__global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-    const int2* __restrict__ items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ out,
-    float* __restrict__ lse, DropoutParams drop) {
+    const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min,
+    float* __restrict__ out, float* __restrict__ lse, DropoutParams drop, int xcd_groups) {
     using C = Cfg<DH>;
-    constexpr int HG = C::HG, QT = C::QT, UW = C::UW, DHS = C::DHS, KS = C::KS, VW = C::VW, NB = C::NB;
-    constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
-    __shared__ __attribute__((aligned(16))) char lds[C::NBUF * C::kTile];
+    using F = FwdGeo<DH>;
+    constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW, NB = C::NB;
+    constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT, QRS = F::QRS, QP = F::QP;
+    static_assert(C::UW == 1, "one (tile, head) unit per wave");
+    __shared__ __attribute__((aligned(16))) char lds[F::kBytes];
+    constexpr int NBUF = F::NBUF;
+    char* const q_lds = lds + NBUF * C::kTile;
+    int32_t* const qtok_lds = reinterpret_cast<int32_t*>(q_lds + 2 * F::kQPlane);
+    int4* const desc = reinterpret_cast<int4*>(q_lds + 2 * F::kQPlane + F::QROWS * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
@@ -70,87 +108,103 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_last;
 #endif
-    const int2 item = items[blockIdx.x];
-    const int n = win_count[item.x], start = win_start[item.x];
-    AKEEP(n); AKEEP(start);
-    ASTAMP(0);  // item record + window geometry (two dependent round trips)
-    const int n_kt = (n + 31) >> 5;
-    const int h0 = blockIdx.y * HG;
+    const int hgn = heads / HG;                 // head groups per item
+    // Work units = (item, head group), head group fastest.  A token row holds all heads, and a head's slice of it is a
+    // fraction of a cache line: the workgroups that read the same rows must share an L2, or every XCD pulls the same lines
+    // over the fabric.  Workgroups are dealt round-robin over the XCDs (blockIdx % xcd_groups labels the workgroups that
+    // share one; placement is a speed matter only), so group x takes the items = x (mod xcd_groups) and walks them with
+    // its own workgroups side by side: at any moment one XCD works on a handful of windows, all heads of each.
+    const int XG = xcd_groups;                  // 1 = flat order
+    const int gx = (int)blockIdx.x % XG, gs = (int)blockIdx.x / XG;
+    const int S = ((int)gridDim.x - gx + XG - 1) / XG;       // workgroups of my group
+    const int units_x = ((n_items - gx + XG - 1) / XG) * hgn;  // units of my group: u = s + j * S
+    const int J = units_x > gs ? (units_x - gs + S - 1) / S : 0;
+    auto unit_of = [&](int j, int* item, int* hg) {
+        const int u = gs + j * S;
+        *item = (u / hgn) * XG + gx;
+        *hg = u % hgn;
+    };
     const float qscale = kLog2e / fmaxf(tau[0], tau_min);
     // every score is <= qscale; p = exp2(s - qscale) >= 2^(-2 qscale) must stay a normal float
     const bool fixed_max = qscale <= 40.0f;
 
-    // ---------------------------------------------------------------- staging role of this thread
+    // resolve descriptors j0 .. j0 + count - 1 of this workgroup into the ring: {first token slot, tokens, tile / chunk, window}
+    auto fill_desc = [&](int j0, int count) {
+        if (tid < count && j0 + tid < J) {
+            int item_i, hg_i;
+            unit_of(j0 + tid, &item_i, &hg_i);
+            const int2 it = items[item_i];
+            desc[(j0 + tid) & (kDescRing - 1)] = make_int4(win_start[it.x], win_count[it.x], it.y, it.x);
+        }
+    };
+
+    // ---------------------------------------------------------------- staging role of this thread: key / value tiles
     const int st_which = tid >> 7;            // 0: K rows, 1: V rows
     const int st_key = (tid & 127) >> 2, st_part = tid & 3;
     const float* st_src = st_which == 0 ? k : v;
     const int st_ld = st_which == 0 ? ldk : ldv;
-    const int st_col = C::kNarrow ? (h0 + C::HPT * st_part) * DH : h0 * DH + st_part * CT;  // first channel of this thread's share
+    // first channel of this thread's share, relative to the head group's first channel
+    const int st_col0 = C::kNarrow ? (C::HPT * st_part) * DH : st_part * CT;
     float st_reg[CT];
-    // token row of this thread's key in tile t: loaded a tile ahead of the rows, so that the row gather is one memory
-    // round trip, not two dependent ones
-    auto load_tok = [&](int t) {
-        int kk = t * 32 + st_key;
-        kk = kk < n ? kk : n - 1;  // clamped rows are finite and masked by p = 0
-        return tok[start + kk];
-    };
-    auto stage_load = [&](int32_t token_row) {
-        const float* row = st_src + (int64_t)token_row * st_ld + st_col;
+    auto load_part = [&](const float* row, float* dst) {
         // widest aligned pieces: the share starts at a multiple of CT floats past a 16-B aligned head-group base
         if constexpr ((CT * 4) % 16 == 0 && (C::kNarrow ? (C::HPT * DH * 4) % 16 == 0 : (DH * 4) % 16 == 0)) {
 #pragma unroll
             for (int i = 0; i < CT / 4; ++i) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * i);
-                st_reg[4 * i] = x[0]; st_reg[4 * i + 1] = x[1]; st_reg[4 * i + 2] = x[2]; st_reg[4 * i + 3] = x[3];
+                dst[4 * i] = x[0]; dst[4 * i + 1] = x[1]; dst[4 * i + 2] = x[2]; dst[4 * i + 3] = x[3];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < CT / 2; ++i) {
                 const f32x2 x = *reinterpret_cast<const f32x2*>(row + 2 * i);
-                st_reg[2 * i] = x[0]; st_reg[2 * i + 1] = x[1];
+                dst[2 * i] = x[0]; dst[2 * i + 1] = x[1];
+            }
+        }
+    };
+    // normalised (x scale) + split image row piece: [row][head][DHS] hi plane, lo plane `plane` bytes behind
+    auto store_norm = [&](const float* reg, float scale, char* row_dst, int plane) {
+        if constexpr (C::kNarrow) {
+#pragma unroll
+            for (int hh = 0; hh < C::HPT; ++hh) {
+                float ss = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) ss = fmaf(reg[hh * DH + d], reg[hh * DH + d], ss);
+                const float r = scale * inv_norm(ss);
+                uint32_t hi[DHS / 2], lo[DHS / 2];
+#pragma unroll
+                for (int i = 0; i < DHS / 2; ++i) {
+                    const float a = 2 * i < DH ? reg[hh * DH + 2 * i] * r : 0.f;
+                    const float b = 2 * i + 1 < DH ? reg[hh * DH + 2 * i + 1] * r : 0.f;
+                    split2(a, b, &hi[i], &lo[i]);
+                }
+                char* p = row_dst + ((C::HPT * st_part + hh) * DHS) * 2;
+#pragma unroll
+                for (int i = 0; i < DHS / 8; ++i) {
+                    *reinterpret_cast<u32x4*>(p + 16 * i) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
+                    *reinterpret_cast<u32x4*>(p + plane + 16 * i) = (u32x4){lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+                }
+            }
+        } else {
+            float ss = 0.f;
+#pragma unroll
+            for (int d = 0; d < CT; ++d) ss = fmaf(reg[d], reg[d], ss);
+            ss = quad_sum(ss);  // the 4 threads of a row hold a quarter of the head each
+            const float r = scale * inv_norm(ss);
+            char* p = row_dst + (st_part * CT) * 2;
+#pragma unroll
+            for (int i = 0; i < CT / 2; ++i) {
+                uint32_t hi, lo;
+                split2(reg[2 * i] * r, reg[2 * i + 1] * r, &hi, &lo);
+                *reinterpret_cast<uint32_t*>(p + 4 * i) = hi;
+                *reinterpret_cast<uint32_t*>(p + plane + 4 * i) = lo;
             }
         }
     };
     auto stage_store = [&](int buf) {
         char* base = lds + buf * C::kTile;
         if (st_which == 0) {  // K: L2-normalise per head, split, row-major [key][head][DHS]
-            char* dst = base + st_key * KRS;
-            if constexpr (C::kNarrow) {
-#pragma unroll
-                for (int hh = 0; hh < C::HPT; ++hh) {
-                    float ss = 0.f;
-#pragma unroll
-                    for (int d = 0; d < DH; ++d) ss = fmaf(st_reg[hh * DH + d], st_reg[hh * DH + d], ss);
-                    const float r = inv_norm(ss);
-                    uint32_t hi[DHS / 2], lo[DHS / 2];
-#pragma unroll
-                    for (int i = 0; i < DHS / 2; ++i) {
-                        const float a = 2 * i < DH ? st_reg[hh * DH + 2 * i] * r : 0.f;
-                        const float b = 2 * i + 1 < DH ? st_reg[hh * DH + 2 * i + 1] * r : 0.f;
-                        split2(a, b, &hi[i], &lo[i]);
-                    }
-                    char* p = dst + ((C::HPT * st_part + hh) * DHS) * 2;
-#pragma unroll
-                    for (int i = 0; i < DHS / 8; ++i) {
-                        *reinterpret_cast<u32x4*>(p + 16 * i) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
-                        *reinterpret_cast<u32x4*>(p + C::kPlane + 16 * i) = (u32x4){lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
-                    }
-                }
-            } else {
-                float ss = 0.f;
-#pragma unroll
-                for (int d = 0; d < CT; ++d) ss = fmaf(st_reg[d], st_reg[d], ss);
-                ss = quad_sum(ss);  // the 4 threads of a key hold a quarter of the head each
-                const float r = inv_norm(ss);
-                char* p = dst + (st_part * CT) * 2;
-#pragma unroll
-                for (int i = 0; i < CT / 2; ++i) {
-                    uint32_t hi, lo;
-                    split2(st_reg[2 * i] * r, st_reg[2 * i + 1] * r, &hi, &lo);
-                    *reinterpret_cast<uint32_t*>(p + 4 * i) = hi;
-                    *reinterpret_cast<uint32_t*>(p + C::kPlane + 4 * i) = lo;
-                }
-            }
+            store_norm(st_reg, 1.0f, base + st_key * KRS, C::kPlane);
         } else {  // V: split only; [key][head][VW] with a 1.0 behind each head's channels (row sum of P for free)
             char* dst = base + 32 * KRS + st_key * VRS;
             if constexpr (C::kNarrow) {
@@ -191,77 +245,13 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
         }
     };
 
-    // The first key tile's gather is issued BEFORE the query prologue: its two dependent round trips (token index, then
-    // the rows) overlap those of the queries instead of following them -- these workgroups live for a few microseconds,
-    // most of it memory latency.
-    int32_t tok_next = n_kt > 1 ? load_tok(1) : 0;
-    {
-        const int32_t tok0 = load_tok(0);
-        AKEEP(tok0);
-        ASTAMP(1);  // token indices of the first key tile
-        stage_load(tok0);
-    }
-
-    // ---------------------------------------------------------------- this wave's (tile, head) units
-    const int n_qt_here = min(QT, n_kt - item.y * QT);  // query tiles of the item that exist
-    bf16x8 q_hi[UW][2][KS], q_lo[UW][2][KS];
-    f32x4 o_acc[UW][2][NB];
-    float m_run[UW][2], l_run[UW][2];
-    int32_t token[UW][2];
-    int q0[UW], hh_of[UW];
-    bool active[UW], two[UW];
-    uint32_t drop_row[UW][2];  // dropout: hash state of this lane's query pair (attn_dropout.hpp), fixed over the key loop
-#pragma unroll
-    for (int un = 0; un < UW; ++un) {
-        const int unit = wave + 4 * un;
-        const int qt = C::kNarrow ? 0 : unit;
-        hh_of[un] = C::kNarrow ? unit : 0;
-        q0[un] = (item.y * QT + qt) * 32;
-        active[un] = qt < n_qt_here;          // wave-uniform
-        two[un] = n - q0[un] > 16;            // the tile's second 16-query group exists (wave-uniform)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int qi = q0[un] + 16 * j + c16;
-            if constexpr (DROPOUT) drop_row[un][j] = dropout_row_state(dropout_head_state(drop, item.x, h0 + hh_of[un]), qi);
-            token[un][j] = -1;
-            m_run[un][j] = -INFINITY;
-            l_run[un][j] = 0.f;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) o_acc[un][j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // a wave without this query group (idle wave of a small window, tile with <= 16 queries) skips the whole
-            // normalise / split prologue: wave-uniform, and those fragments are never multiplied
-            if (!active[un] || (j == 1 && !two[un])) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) q_hi[un][j][s] = q_lo[un][j][s] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
-                continue;
-            }
-            float x[KS][8];
-            float ss = 0.f;
-            const bool have = qi < n;
-            if (have) token[un][j] = tok[start + qi];
-            const float* row = q + (int64_t)(have ? token[un][j] : 0) * ldq + (h0 + hh_of[un]) * DH;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c0 = 32 * s + 8 * g + 2 * i;
-                    f32x2 xv = {0.f, 0.f};
-                    if (have && c0 < DH) xv = *reinterpret_cast<const f32x2*>(row + c0);
-                    x[s][2 * i] = xv[0];
-                    x[s][2 * i + 1] = xv[1];
-                    ss = fmaf(xv[0], xv[0], fmaf(xv[1], xv[1], ss));
-                }
-            ss += __shfl_xor(ss, 16, SEG3D_WAVE);
-            ss += __shfl_xor(ss, 32, SEG3D_WAVE);
-            const float r = qscale * inv_norm(ss);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) x[s][i] *= r;
-                split_frag(x[s], &q_hi[un][j][s], &q_lo[un][j][s]);
-            }
-        }
-    }
+    // ---------------------------------------------------------------- staging role: the item's query rows
+    // narrow heads: 32 rows x 4 heads, threads 0 .. 127 (one head of one row each); wide heads: up to 128 rows of one head,
+    // two passes of 64 rows x 4 threads
+    const bool q_role = C::kNarrow ? tid < 128 : true;
+    const int q_row0 = C::kNarrow ? (tid & 127) >> 2 : tid >> 2;  // + 64 per pass
+    float q_reg[QP][CT];
+    int32_t q_tok[QP];
 
     // ---------------------------------------------------------------- fragment reads of a staged tile
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -292,159 +282,282 @@ __global__ __launch_bounds__(256, (DROPOUT && Cfg<DH>::kWaves > 3 ? 3 : Cfg<DH>:
         *lo = __builtin_bit_cast(bf16x8, (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
     };
 
-    // ---------------------------------------------------------------- one key tile for one unit
-    auto tile_step = [&](auto fixed_tag, int un, int t, const char* base) {
-        constexpr bool FIXED = decltype(fixed_tag)::value;
-        const bool last = t + 1 == n_kt;
-        const int hh = hh_of[un];
-        bf16x8 k_hi[2][KS], k_lo[2][KS], v_hi[NB], v_lo[NB];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) read_k(base, hh, u, s, &k_hi[u][s], &k_lo[u][s]);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) read_vt(base, hh, b, &v_hi[b], &v_lo[b]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !two[un]) break;
-            float sc[8];
-            const float init = FIXED ? -qscale : 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x4 acc = {init, init, init, init};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc = mfma3(k_hi[u][s], k_lo[u][s], q_hi[un][j][s], q_lo[un][j][s], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sc[u * 4 + r] = acc[r];
-            }
-            float alpha = 1.0f;
-            if constexpr (FIXED) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
-                if (last) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = 0.f;
-                }
-            } else {
-                if (last) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = -INFINITY;
-                }
-                float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, SEG3D_WAVE));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, SEG3D_WAVE));
-                const float m_new = fmaxf(m_run[un][j], tmax);
-                alpha = __builtin_amdgcn_exp2f(m_run[un][j] - m_new);
-                m_run[un][j] = m_new;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_new);
-            }
-            if constexpr (DROPOUT || !C::kOnes || !FIXED) {
-                // row sum on the vector ALUs (per-lane partial: the lanes of a query column are summed once, at the end)
-                float ps = ((sc[0] + sc[1]) + (sc[2] + sc[3])) + ((sc[4] + sc[5]) + (sc[6] + sc[7]));
-                l_run[un][j] = fmaf(l_run[un][j], alpha, ps);
-            }
-            if constexpr (DROPOUT) {
-                // keys 4g .. 4g+3 of each 16-key half = two 2 x 2 blocks shared with lane c16 ^ 1 (same query pair):
-                // the even lane hashes the first, the odd lane the second, one DPP swap (dropout_pair_bits)
-                const int qi = q0[un] + 16 * j + c16;
-                const bool odd = c16 & 1;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int kj = t * 32 + u * 16 + 4 * g;
-                    uint32_t bits[2];
-                    dropout_pair_bits(dropout_block_bits(drop_row[un][j], dropout_key_term(kj + (odd ? 2 : 0))), odd, &bits[0], &bits[1]);
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2) {
-                        if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2)) sc[u * 4 + 2 * r2] = 0.f;
-                        if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2 + 1)) sc[u * 4 + 2 * r2 + 1] = 0.f;
-                    }
-                }
-            }
-            bf16x8 p_hi, p_lo;
-            split_frag(sc, &p_hi, &p_lo);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                f32x4 acc = o_acc[un][j][b];
-                if constexpr (!FIXED) acc = acc * alpha;
-                o_acc[un][j][b] = mfma3(v_hi[b], v_lo[b], p_hi, p_lo, acc);
-            }
-        }
-    };
+    // this wave's unit inside an item: narrow = head `wave` of the 32-query tile, wide = query tile `wave` of the head
+    const int qt = C::kNarrow ? 0 : wave;
+    const int hh = C::kNarrow ? wave : 0;
 
-    // ---------------------------------------------------------------- epilogue of a unit
-    auto finish = [&](bool fixed, int un) {
-        const int h = h0 + hh_of[un];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j == 1 && !two[un]) break;
-            float l;
-            if (C::kOnes && !DROPOUT && fixed) {  // the ones column: d = DH lives in block DH / 16, lane group (DH % 16) / 4
-                constexpr int b1 = DH / 16, g1 = (DH % 16) / 4, r1 = DH % 4;
-                l = __shfl(o_acc[un][j][b1][r1], c16 + 16 * g1, SEG3D_WAVE);
-            } else {
-                l = l_run[un][j];
-                l += __shfl_xor(l, 16, SEG3D_WAVE);
-                l += __shfl_xor(l, 32, SEG3D_WAVE);
-            }
-            if (token[un][j] < 0) continue;
-            const float inv = (DROPOUT ? drop.inv_keep : 1.0f) * __builtin_amdgcn_rcpf(l);  // 1 ulp; products carry 2^-16
-            float* op = out + (int64_t)token[un][j] * (heads * DH) + h * DH;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int d = 16 * b + 4 * g;
-                const f32x4 o = o_acc[un][j][b] * inv;
-                if (DH % 4 == 0) {
-                    if (d < DH) *reinterpret_cast<f32x4*>(op + d) = o;
-                } else {
-                    if (d + 1 < DH) *reinterpret_cast<f32x2*>(op + d) = (f32x2){o[0], o[1]};
-                    if (d + 3 < DH) *reinterpret_cast<f32x2*>(op + d + 2) = (f32x2){o[2], o[3]};
-                }
-            }
-            const float mx = fixed ? qscale : m_run[un][j];
-            if (lse && g == 0) lse[(int64_t)token[un][j] * heads + h] = (mx + __builtin_amdgcn_logf(l)) * kLn2;
-        }
-    };
-
-    // ---------------------------------------------------------------- main loop over the window's key tiles
     auto run = [&](auto fixed_tag) {
-        ASTAMP(2);  // query prologue (token, row gather, normalise, split)
-        stage_store(0);
-        ASTAMP(3);  // wait for the first key tile's rows + convert + LDS store
+        constexpr bool FIXED = decltype(fixed_tag)::value;
+        if (J == 0) return;  // (workgroup-uniform)
+        fill_desc(0, kDescRing);
         __syncthreads();
-        ASTAMP(4);  // barriers
-        for (int t = 0; t < n_kt; ++t) {
-            const bool more = t + 1 < n_kt;
-            const int buf = C::NBUF == 2 ? (t & 1) : 0;
-            if (more) {
-                stage_load(tok_next);  // in flight while this tile is multiplied
-                if (t + 2 < n_kt) tok_next = load_tok(t + 2);
-            }
+        ASTAMP(0);  // descriptors of the workgroup (once)
+        // ---- item 0: its token indices and rows are fetched here, in the open; every later item's ride under arithmetic
+        int4 cur = desc[0];
+        int32_t tok_next = 0;
+        auto fetch_tokens = [&](const int4& d, int32_t* t0, int32_t* t1, int32_t* tq) {
+            const int nn = d.y, ns = d.x;
+            *t0 = tok[ns + (st_key < nn ? st_key : nn - 1)];
+            *t1 = nn > 32 ? tok[ns + (32 + st_key < nn ? 32 + st_key : nn - 1)] : 0;
 #pragma unroll
-            for (int un = 0; un < UW; ++un)
-                if (active[un]) tile_step(fixed_tag, un, t, lds + buf * C::kTile);
-            ASTAMP(5);  // tile compute (LDS fragment reads, MFMAs, softmax)
-            if (C::NBUF == 1) __syncthreads();  // everyone is done with the only buffer
-            ASTAMP(4);
-            if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0);
+            for (int p = 0; p < QP; ++p) {
+                const int qi = d.z * QT * 32 + q_row0 + 64 * p;
+                tq[p] = q_role ? tok[ns + (qi < nn ? qi : nn - 1)] : 0;
+            }
+        };
+        auto request_rows = [&](const int4& d, int h0r, int32_t t0, const int32_t* tq) {
+            load_part(st_src + (int64_t)t0 * st_ld + h0r * DH + st_col0, st_reg);
+#pragma unroll
+            for (int p = 0; p < QP; ++p) {
+                q_tok[p] = tq[p];
+                if (q_role && (p == 0 || d.y - d.z * QT * 32 > 64))
+                    load_part(q + (int64_t)tq[p] * ldq + h0r * DH + st_col0, q_reg[p]);
+            }
+        };
+        {
+            int32_t t0, tq[QP];
+            fetch_tokens(cur, &t0, &tok_next, tq);
+            int item0, hg0;
+            unit_of(0, &item0, &hg0);
+            request_rows(cur, hg0 * HG, t0, tq);
+        }
+        ASTAMP(1);
+
+        for (int j = 0; j < J; ++j) {
+            const int n = cur.y, start = cur.x, win = cur.w;
+            int item_j, hg_j;
+            unit_of(j, &item_j, &hg_j);
+            const int h0 = hg_j * HG;
+            const int n_kt = (n + 31) >> 5;
+            const int q_base = cur.z * QT * 32;        // first query of the item
+            const int n_q = min(QT * 32, n - q_base);  // its queries
+            if (j > 0 && (j & (kDescRing / 2 - 1)) == 0) fill_desc(j + kDescRing / 2, kDescRing / 2);  // refill the dead half
+
+            // ---- (A) park the query image and the first key tile
+#pragma unroll
+            for (int p = 0; p < QP; ++p) {
+                if (q_role && (p == 0 || n_q > 64)) {
+                    const int row = q_row0 + 64 * p;
+                    store_norm(q_reg[p], qscale, q_lds + row * QRS, F::kQPlane);
+                    if (st_part == 0) qtok_lds[row] = q_base + row < n ? q_tok[p] : -1;
+                }
+            }
+#ifdef SEG3D_ATTN_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ASTAMP(1);  // (diagnostic build) waiting for prefetched rows
+#endif
+            stage_store(0);
             ASTAMP(3);
             __syncthreads();
             ASTAMP(4);
+
+            // ---- (B) this wave's query fragments
+            const int q0 = q_base + qt * 32;
+            const bool active = qt * 32 < n_q;       // wave-uniform
+            const bool two = n - q0 > 16;            // the tile's second 16-query group exists (wave-uniform)
+            bf16x8 q_hi[2][KS], q_lo[2][KS];
+            f32x4 o_acc[2][NB];
+            float m_run[2], l_run[2];
+            int32_t token[2];
+            uint32_t drop_row[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                m_run[jj] = -INFINITY;
+                l_run[jj] = 0.f;
+                token[jj] = -1;
+                drop_row[jj] = 0u;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) o_acc[jj][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bool have = active && (jj == 0 || two);
+                const int row = qt * 32 + 16 * jj + c16;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int c0 = 32 * s + 8 * g;
+                    u32x4 a = zero4, b = zero4;
+                    if (have && c0 < DHS) {
+                        const char* p = q_lds + row * QRS + (hh * DHS + c0) * 2;
+                        a = *reinterpret_cast<const u32x4*>(p);
+                        b = *reinterpret_cast<const u32x4*>(p + F::kQPlane);
+                    }
+                    q_hi[jj][s] = __builtin_bit_cast(bf16x8, a);
+                    q_lo[jj][s] = __builtin_bit_cast(bf16x8, b);
+                }
+                if (have) token[jj] = qtok_lds[row];
+                if constexpr (DROPOUT) drop_row[jj] = dropout_row_state(dropout_head_state(drop, win, h0 + hh), q0 + 16 * jj + c16);
+            }
+
+            // ---- (C) token indices of the next item (first two key tiles, query rows): in flight under this item's tiles.
+            // (Fetching them an item earlier and requesting the rows at the start of the last key tile was tried: the row
+            // wait fell from 20 % to 11 % of a wave's time, the extra live registers cost more -- 1.57 -> 1.80 ms.)
+            const bool more_items = j + 1 < J;
+            int4 nxt = cur;
+            int32_t n_tok0 = 0, n_tok1 = 0, nq_tok[QP];
+#pragma unroll
+            for (int p = 0; p < QP; ++p) nq_tok[p] = 0;
+            if (more_items) {
+                nxt = desc[(j + 1) & (kDescRing - 1)];
+                fetch_tokens(nxt, &n_tok0, &n_tok1, nq_tok);
+            }
+
+            // ---- (D) the window's key tiles
+            auto load_tok = [&](int t) {
+                int kk = t * 32 + st_key;
+                kk = kk < n ? kk : n - 1;  // clamped rows are finite and masked by p = 0
+                return tok[start + kk];
+            };
+            for (int t = 0; t < n_kt; ++t) {
+                const bool more = t + 1 < n_kt;
+                const int buf = NBUF == 2 ? (t & 1) : 0;
+                if (more) {
+                    load_part(st_src + (int64_t)tok_next * st_ld + h0 * DH + st_col0, st_reg);  // in flight while this tile is multiplied
+                    if (t + 2 < n_kt) tok_next = load_tok(t + 2);
+                }
+                if (active) {
+                    const char* base = lds + buf * C::kTile;
+                    const bool last = t + 1 == n_kt;
+                    bf16x8 k_hi[2][KS], k_lo[2][KS], v_hi[NB], v_lo[NB];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) read_k(base, hh, u, s, &k_hi[u][s], &k_lo[u][s]);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) read_vt(base, hh, b, &v_hi[b], &v_lo[b]);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        if (jj == 1 && !two) break;
+                        float sc[8];
+                        const float init = FIXED ? -qscale : 0.f;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            f32x4 acc = {init, init, init, init};
+#pragma unroll
+                            for (int s = 0; s < KS; ++s) acc = mfma3(k_hi[u][s], k_lo[u][s], q_hi[jj][s], q_lo[jj][s], acc);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sc[u * 4 + r] = acc[r];
+                        }
+                        float alpha = 1.0f;
+                        if constexpr (FIXED) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
+                            if (last) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i)
+                                    if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = 0.f;
+                            }
+                        } else {
+                            if (last) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i)
+                                    if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = -INFINITY;
+                            }
+                            float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+                            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, SEG3D_WAVE));
+                            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, SEG3D_WAVE));
+                            const float m_new = fmaxf(m_run[jj], tmax);
+                            alpha = __builtin_amdgcn_exp2f(m_run[jj] - m_new);
+                            m_run[jj] = m_new;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_new);
+                        }
+                        if constexpr (DROPOUT || !C::kOnes || !FIXED) {
+                            // row sum on the vector ALUs (per-lane partial: the lanes of a query column are summed once, at the end)
+                            float ps = ((sc[0] + sc[1]) + (sc[2] + sc[3])) + ((sc[4] + sc[5]) + (sc[6] + sc[7]));
+                            l_run[jj] = fmaf(l_run[jj], alpha, ps);
+                        }
+                        if constexpr (DROPOUT) {
+                            // keys 4g .. 4g+3 of each 16-key half = two 2 x 2 blocks shared with lane c16 ^ 1 (same query pair):
+                            // the even lane hashes the first, the odd lane the second, one DPP swap (dropout_pair_bits)
+                            const int qi = q0 + 16 * jj + c16;
+                            const bool odd = c16 & 1;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int kj = t * 32 + u * 16 + 4 * g;
+                                uint32_t bits[2];
+                                dropout_pair_bits(dropout_block_bits(drop_row[jj], dropout_key_term(kj + (odd ? 2 : 0))), odd, &bits[0], &bits[1]);
+#pragma unroll
+                                for (int r2 = 0; r2 < 2; ++r2) {
+                                    if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2)) sc[u * 4 + 2 * r2] = 0.f;
+                                    if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2 + 1)) sc[u * 4 + 2 * r2 + 1] = 0.f;
+                                }
+                            }
+                        }
+                        bf16x8 p_hi, p_lo;
+                        split_frag(sc, &p_hi, &p_lo);
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            f32x4 acc = o_acc[jj][b];
+                            if constexpr (!FIXED) acc = acc * alpha;
+                            o_acc[jj][b] = mfma3(v_hi[b], v_lo[b], p_hi, p_lo, acc);
+                        }
+                    }
+                }
+                ASTAMP(5);  // tile compute (LDS fragment reads, MFMAs, softmax)
+                if (NBUF == 1) __syncthreads();  // everyone is done with the only buffer
+                ASTAMP(4);
+#ifdef SEG3D_ATTN_STAMP
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ASTAMP(1);
+#endif
+                if (more) stage_store(NBUF == 2 ? (buf ^ 1) : 0);
+                ASTAMP(3);
+                __syncthreads();
+                ASTAMP(4);
+            }
+
+            // ---- (E) the next item's rows: requested before this item's epilogue, needed at the top of the next round
+            if (more_items) {
+                int item_n, hg_n;
+                unit_of(j + 1, &item_n, &hg_n);
+                request_rows(nxt, hg_n * HG, n_tok0, nq_tok);
+                tok_next = n_tok1;
+            }
+
+            // ---- (F) epilogue of this item's unit
+            if (active) {
+                const int h = h0 + hh;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (jj == 1 && !two) break;
+                    float l;
+                    if constexpr (C::kOnes && !DROPOUT && FIXED) {  // the ones column: d = DH lives in block DH / 16, lane group (DH % 16) / 4
+                        constexpr int b1 = DH / 16, g1 = (DH % 16) / 4, r1 = DH % 4;
+                        l = __shfl(o_acc[jj][b1][r1], c16 + 16 * g1, SEG3D_WAVE);
+                    } else {
+                        l = l_run[jj];
+                        l += __shfl_xor(l, 16, SEG3D_WAVE);
+                        l += __shfl_xor(l, 32, SEG3D_WAVE);
+                    }
+                    if (token[jj] < 0) continue;
+                    const float inv = (DROPOUT ? drop.inv_keep : 1.0f) * __builtin_amdgcn_rcpf(l);  // 1 ulp; products carry 2^-16
+                    float* op = out + (int64_t)token[jj] * (heads * DH) + h * DH;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int d = 16 * b + 4 * g;
+                        const f32x4 o = o_acc[jj][b] * inv;
+                        if (DH % 4 == 0) {
+                            if (d < DH) *reinterpret_cast<f32x4*>(op + d) = o;
+                        } else {
+                            if (d + 1 < DH) *reinterpret_cast<f32x2*>(op + d) = (f32x2){o[0], o[1]};
+                            if (d + 3 < DH) *reinterpret_cast<f32x2*>(op + d + 2) = (f32x2){o[2], o[3]};
+                        }
+                    }
+                    const float mx = FIXED ? qscale : m_run[jj];
+                    if (lse && g == 0) lse[(int64_t)token[jj] * heads + h] = (mx + __builtin_amdgcn_logf(l)) * kLn2;
+                }
+            }
+            ASTAMP(6);
+            cur = nxt;
         }
     };
     if (fixed_max) run(std::true_type{});
     else run(std::false_type{});
-#pragma unroll
-    for (int un = 0; un < UW; ++un)
-        if (active[un]) finish(fixed_max, un);
 #ifdef SEG3D_ATTN_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ASTAMP(6);  // epilogue (normalise, stores)
+    ASTAMP(6);
     if (g_attn_stamp_buf && lane == 0) {
-        unsigned long long* o = g_attn_stamp_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        unsigned long long* o = g_attn_stamp_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
         st_acc[7] = st_last - st_begin;
+        st_acc[2] = (unsigned long long)J;
         for (int i = 0; i < 8; ++i) o[i] = st_acc[i];
     }
 #endif
@@ -458,13 +571,29 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
     using C = Cfg<DH>;
     const int2* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
-    const dim3 grid((unsigned)n_items, (unsigned)(heads / C::HG));
+    // one round of resident workgroups (persistent): CUs x workgroups per CU, or fewer when there is less work
+    static const int n_cu = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    static const int per_cu_env = getenv("SEG3D_ATTN_WGS_PER_CU") ? atoi(getenv("SEG3D_ATTN_WGS_PER_CU")) : 0;  // A/B
+    const int per_cu = per_cu_env > 0 ? per_cu_env : FwdGeo<DH>::waves(drop.threshold != 0);
+    const long long total = (long long)n_items * (heads / C::HG);
+    static const int xcd_env = getenv("SEG3D_ATTN_XCD") ? atoi(getenv("SEG3D_ATTN_XCD")) : 8;  // A/B: 1 = flat order
+    const int xg = xcd_env > 0 ? xcd_env : 8;
+    long long wgs = total < (long long)n_cu * per_cu ? total : (long long)n_cu * per_cu;
+    wgs = (wgs + xg - 1) / xg * xg;  // whole groups (a workgroup without units returns at once)
+    const dim3 grid((unsigned)wgs);
     if (drop.threshold)
         hipLaunchKernelGGL((attn_fused_fwd<DH, true>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, tok, win_start, win_count,
-                           items, heads, tau, tau_min, out, lse, drop);
+                           items, n_items, heads, tau, tau_min, out, lse, drop, xg);
     else
         hipLaunchKernelGGL((attn_fused_fwd<DH, false>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, tok, win_start, win_count,
-                           items, heads, tau, tau_min, out, lse, drop);
+                           items, n_items, heads, tau, tau_min, out, lse, drop, xg);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

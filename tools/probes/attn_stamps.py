@@ -2,8 +2,9 @@
 
 Needs a library built with -DSEG3D_ATTN_STAMP on attention_fused.hip (tools/probes/build_attn_stamp_lib.sh puts it in
 csrc/libS.so; on the GPU box: cp libS.so libseg3d_hip.so for this probe only).
-phases: 0 item record + window geometry  1 first token indices  2 query prologue  3 key/value rows: wait + convert + LDS
-        store  4 barriers  5 tile compute (LDS reads, MFMAs, softmax)  6 epilogue  7 whole wave
+phases (persistent kernel, sums over the items a workgroup walks): 0 descriptors of the workgroup (once)  1 first item's
+        token indices + row requests  3 rows: wait + convert + LDS store  4 barriers  5 tile compute (LDS reads, MFMAs,
+        softmax) incl. the next item's index prefetch  6 next item's row requests + epilogue  7 whole wave; slot 2 = items
 python tools/probes/attn_stamps.py [--workload dense2m]
 """
 import ctypes
@@ -30,7 +31,7 @@ def main():
     fn.restype = ctypes.c_int
     buf = torch.zeros((1 << 20) * 4 * 8, dtype=torch.int64, device=dev)
     assert fn(buf.data_ptr()) == 0
-    names = ["item", "tok", "qprol", "kvstage", "barrier", "compute", "epilog", "total"]
+    names = ["desc", "rowwait", "items", "convert", "barrier", "compute", "epilog", "total"]
     for stage, c in enumerate((48, 96, 192, 384)):
         part = swformer.SparseWindowPartitionLayer(info[stage], cfg.MODEL.WINDOW_SHAPE, [float(g) / 2 ** stage for g in ds.grid_size])
         plan = part.plan(level.coords, 1, c)
@@ -48,10 +49,10 @@ def main():
         mean = s.mean(dim=(0, 1))
         tot = float(mean[7])
         wg_life = s[:, :, 7].max(dim=1).values
-        print(f"stage {stage + 1} C={c} wgs {s.shape[0]:6d} mean wave {tot:8.0f} cyc  " +
-              "  ".join(f"{names[i]} {float(mean[i]) / tot * 100:4.1f}%" for i in range(7)) +
-              f"  | wg life mean {float(wg_life.mean()):8.0f} p90 {float(wg_life.quantile(0.9)):8.0f} max {float(wg_life.max()):8.0f}"
-              f"  sum wg life / 1024 slots {float(wg_life.sum()) / 1024 / 2.4e3:7.1f} us@2.4GHz", flush=True)
+        print(f"stage {stage + 1} C={c} wgs {s.shape[0]:6d} items/wg {float(mean[2]):6.1f} mean wave {tot:8.0f} cyc  " +
+              "  ".join(f"{names[i]} {float(mean[i]) / tot * 100:4.1f}%" for i in (0, 1, 3, 4, 5, 6)) +
+              f"  | wg life mean {float(wg_life.mean()):8.0f} min {float(wg_life.min()):8.0f} max {float(wg_life.max()):8.0f}"
+              f"  = {float(wg_life.max()) / 2.4e3:6.1f} us@2.4GHz", flush=True)
         if stage < 3:
             level = level.down()[0]
 

@@ -1,0 +1,8 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r3d3
+timeout -k 10 600 python -m pytest tests/test_gpu_attention.py -x -q > gpurun_out/r3d3/tests_attn.txt 2>&1; echo attn tests rc=$?
+timeout -k 10 300 python -m pytest tests/test_gpu_training.py -x -q -k "probe" > gpurun_out/r3d3/tests_probe.txt 2>&1; echo probe rc=$?
+bash tools/ab_lib.sh "python tools/attn_bench.py" 2 > gpurun_out/r3d3/ab.txt 2>&1; echo ab rc=$?
+cp openseg3d_amd/csrc/libS.so openseg3d_amd/csrc/libseg3d_hip.so
+python tools/probes/attn_stamps.py > gpurun_out/r3d3/stamps.txt 2>&1; echo stamps rc=$?
+cp openseg3d_amd/csrc/libB.so openseg3d_amd/csrc/libseg3d_hip.so
