@@ -255,6 +255,13 @@ def parity_report(pts, n_cur, image, ds, model, dev, oracle_res, oracle_coords, 
             out[name] = float((res[key].float().cpu() - oracle_res[key]).abs().max())
     if ids_ok:
         out["max_abs_logit"] = float(oracle_res["point_out"].abs().max())
+        out["max_rel_logit_diff"] = out["max_abs_logit_diff"] / max(out["max_abs_logit"], 1e-30)
+    # what the checker itself is pinned by
+    out["pinned_by"] = ("oracle/ = CPU restatement checked against outputs of the reference's own Python (tests/golden/*.npz, "
+                        "regenerable with tests/golden/make_golden.py) for voxelizer, window partition, attention, "
+                        "Segformer / SPNet wiring and losses; spconv and torch_scatter are absent third-party packages "
+                        "(requirements.txt:4,8): their restatement is cross-checked against dense F.conv3d / conv_transpose3d "
+                        "only (tests/test_oracle_sparse_conv.py)")
     return out
 
 

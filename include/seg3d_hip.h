@@ -284,17 +284,23 @@ int seg3d_pos_embed(const int32_t* in_win, int64_t m, const int32_t* win_xyz /*h
  *   (log-sum-exp per query row, kept for the backward).  m = number of voxel rows; dh in {6,12,24,48}
  *   (8 heads on 48/96/192/384 channels, pointtransformer.py:141-157).
  * Forward runs on the matrix cores in split-bf16 arithmetic (q, k, v, P as bf16 hi + lo, three
- * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate and softmax) in ONE launch per layer: a workgroup per
- * (32-query tile, all 8 heads) for dh 6 / 12 (tile_item) or per (128-query chunk, head) for dh 24 / 48 (qg_item)
- * gathers, normalises and splits the window's k / v rows itself, 32 keys at a time, through LDS;
- * n_tiles / n_qgroups are counts[2..3] of seg3d_window_partition.
+ * v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate and softmax) in ONE launch per layer of PERSISTENT workgroups:
+ * each walks its share of the work items -- (32-query tile, 4 heads) for dh 6 / 12 (tile_item), (128-query chunk, head)
+ * for dh 24 / 48 (qg_item: the second field counts 128-token chunks, four 32-token tiles) -- gathers, normalises and
+ * splits the item's query rows and the window's k / v rows itself, 32 keys at a time, through LDS, and requests the next
+ * item's rows while the current one is multiplied; n_tiles / n_qgroups are counts[2..3] of seg3d_window_partition.
  * dropout_p / dropout_seed: attention-probability dropout of training mode (cosine_msa.py:172-174); 0 = none.
  * The mask is a function of (seed, window, head, query, key) only -- the backward is given the same two values
  * and regenerates it.  Drop probability is rounded to a multiple of 1/256 and compensated exactly.
  * Backward takes the forward's out and lse, returns gradients w.r.t. the raw q, k, v (through the
  * normalisation) and stores the tau gradient in dtau[0] (per-wave partials in the workspace, summed in a
  * fixed order: the whole backward is free of atomics and identical from run to run).
+ * Head geometries: dh 6 / 12 with a head count that is a multiple of 4 (dh 6: <= 8 heads), dh 24 / 48 with up to 16 heads
+ * (the reference builds 8 heads of 6 / 12 / 24 / 48 channels, pointtransformer.py:143-155); seg3d_window_attn_supported
+ * returns 1 for those, everything else is refused with SEG3D_EINVAL.  win_tile0 is accepted and ignored (it served
+ * kernels removed in ABI 30); the forward needs no workspace, seg3d_window_attn_workspace_bytes sizes the backward's.
  */
+int seg3d_window_attn_supported(int32_t heads, int32_t dh);
 size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t n_tiles, int32_t heads, int32_t dh);
 int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_t ldq, int32_t ldk,
                           int32_t ldv, const int32_t* tok, const int32_t* win_start,

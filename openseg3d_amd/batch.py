@@ -43,3 +43,58 @@ def make_batch(samples, voxel_size, point_cloud_range, device="cuda", cylinder=F
     pts = collate_points(samples, device)
     offsets = np.cumsum([s.shape[0] for s in samples]).tolist()
     return batch_from_resident(pts, offsets, voxel_size, point_cloud_range, cylinder=cylinder)
+
+
+class VoxelGenerator:
+    """``seg3d.core.voxel.VoxelGenerator`` (voxel_generator.py:5-52) on the device voxelizer: same constructor, same
+    ``voxel_size`` / ``point_cloud_range`` / ``grid_size`` attributes (float32 / float32 / int64 numpy arrays, the grid
+    rounded in float32 exactly as voxel_generator.py:15-18), same ``generate(points)`` contract
+
+        points [N, >= 3] float32 / float64  ->  (coors int32 [M, 3] as (z, y, x) in first-seen order,
+                                                  point_voxel_ids int32 [N], -1 = out of range)
+
+    with the subtract and the true divide done in the points' own dtype.  A numpy array goes to the GPU
+    and the result comes back as numpy (the call sites waymo_dataset.py:275 and test_time_aug.py:33 index it as numpy); a
+    CUDA tensor stays on the device and returns tensors (the fast path for TTA, whose 36 re-voxelizations per frame
+    then never leave the card).  There is no CPU implementation behind this class: the product path has no CPU fallback
+    by rule, so a DataLoader worker without a GPU context keeps the reference's numba voxelizer."""
+
+    def __init__(self, voxel_size, point_cloud_range, device="cuda"):
+        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        voxel_size = np.array(voxel_size, dtype=np.float32)
+        grid_size = (point_cloud_range[3:] - point_cloud_range[:3]) / voxel_size
+        self._voxel_size = voxel_size
+        self._point_cloud_range = point_cloud_range
+        self._grid_size = np.round(grid_size).astype(np.int64)
+        self._device = device
+
+    def generate(self, points):
+        """Generate voxels given points (voxel_generator.py:24-26, 55-95)."""
+        as_numpy = isinstance(points, np.ndarray)
+        pts = torch.from_numpy(np.ascontiguousarray(points)).to(self._device) if as_numpy else points
+        if pts.dim() != 2 or pts.shape[1] < 3:
+            raise ValueError("points must be [N, >= 3]")
+        coords, ids = ops.voxelize(pts, self._voxel_size.tolist(), self._point_cloud_range.tolist())
+        coors = coords[:, 1:].contiguous()  # the device voxelizer carries a batch column: (b, z, y, x) -> (z, y, x)
+        if as_numpy:
+            return coors.cpu().numpy(), ids.cpu().numpy()
+        return coors, ids
+
+    @property
+    def voxel_size(self):
+        """list[float]: Size of a single voxel."""
+        return self._voxel_size
+
+    @property
+    def point_cloud_range(self):
+        """list[float]: Range of point cloud."""
+        return self._point_cloud_range
+
+    @property
+    def grid_size(self):
+        """np.ndarray: The size of grids."""
+        return self._grid_size
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(voxel_size={self._voxel_size}, point_cloud_range="
+                f"{self._point_cloud_range.tolist()}, grid_size={self._grid_size.tolist()})")

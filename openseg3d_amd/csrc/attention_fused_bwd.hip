@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
     const float* __restrict__ out, const float* __restrict__ dout, const float* __restrict__ lse,
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-    const int2* __restrict__ items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq, int lddq,
-    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, float* __restrict__ tau_part, DropoutParams drop) {
+    const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
+    int lddq, float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, float* __restrict__ tau_part,
+    DropoutParams drop) {
     using C = Cfg<DH>;
     constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW;
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
@@ -87,10 +88,21 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int2 item = items[blockIdx.x];
+    // Block -> (item, head group): the head groups of one item run side by side on ONE XCD (blocks are dealt round-robin
+    // over the 8 XCDs, so block % 8 labels the blocks that share an L2): a head's slice of a token row is a fraction of a
+    // cache line, and the groups would otherwise pull the same lines over the fabric once per XCD (see attention_fused.hip)
+    constexpr int XG = 8;
+    const int hgn = heads / HG;
+    const int gx = (int)blockIdx.x % XG, gu = (int)blockIdx.x / XG;
+    const int item_i = (gu / hgn) * XG + gx;
+    if (item_i >= n_items) {  // (padding of the last group)
+        if (MODE == 0 && tau_part && lane == 0) tau_part[(size_t)blockIdx.x * 4 + wave] = 0.f;
+        return;
+    }
+    const int2 item = items[item_i];
     const int n = win_count[item.x], start = win_start[item.x];
     const int n_t = (n + 31) >> 5;  // 32-token tiles of the window (streamed and stationary alike)
-    const int h0 = blockIdx.y * HG;
+    const int h0 = (gu % hgn) * HG;
     const int c_all = heads * DH;
     const float tau_c = fmaxf(tau[0], tau_min);
     const float qscale = kLog2e / tau_c;
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     }
 
     // ---------------------------------------------------------------- epilogue
-    float* tau_slot = tau_part ? tau_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave : nullptr;
+    float* tau_slot = tau_part ? tau_part + (size_t)blockIdx.x * 4 + wave : nullptr;
     if (!active) {
         if (MODE == 0 && lane == 0) *tau_slot = 0.f;
         return;
@@ -530,6 +542,9 @@ __global__ __launch_bounds__(1024) void tau_reduce_fused(const float* __restrict
     }
 }
 
+// blocks of a pass: whole groups of 8 items x head groups (the kernel's block -> (item, head group) map)
+static size_t bwd_blocks(int n_items, int hgn) { return (size_t)((n_items + 7) / 8) * 8 * hgn; }
+
 template <int DH>
 int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out, const float* dout,
            const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count, const int2* tile_item,
@@ -538,14 +553,14 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
     using C = Cfg<DH>;
     const int2* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
-    const dim3 grid((unsigned)n_items, (unsigned)(heads / C::HG));
+    const dim3 grid((unsigned)(bwd_blocks(n_items, heads / C::HG)));
     hipLaunchKernelGGL((attn_fused_bwd<DH, 0>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
-                       win_count, items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, drop);
+                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, drop);
     SEG3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(tau_reduce_fused, dim3(1), dim3(1024), 0, st, tau_part, (int)(grid.x * grid.y * 4), dtau);
+    hipLaunchKernelGGL(tau_reduce_fused, dim3(1), dim3(1024), 0, st, tau_part, (int)(grid.x * 4), dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_fused_bwd<DH, 1>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
-                       win_count, items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, drop);
+                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, drop);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -557,14 +572,13 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
 // accumulators in AGPRs), and is still ahead of the three-launch MFMA passes with their prepared-operand round trip
 // (3 layers of the headline scene, dropout on: 1.58 -> 1.11 ms).  Measured per layer: dh 12 1540 -> 617 us, dh 24 780 -> 520 us
 bool attn_fused_bwd_supported(int heads, int dh) {
-    static const bool all = getenv("SEG3D_ATTN_FUSED_BWD_ALL") != nullptr;  // A/B: also dh 6
-    return ((dh == 12 || (all && dh == 6)) && heads % 4 == 0) || dh == 24 || dh == 48;
+    return (dh == 12 && heads % 4 == 0) || dh == 24 || dh == 48;
 }
 
 // floats of workspace the fused backward needs (one dtau partial per wave of pass Q)
 size_t attn_fused_bwd_workspace_bytes(int n_tiles, int n_chunks, int heads, int dh) {
-    const size_t items = (dh <= 12) ? (size_t)n_tiles * (heads / 4) : (size_t)n_chunks * heads;
-    return items * 4 * sizeof(float) + 256;
+    const size_t blocks = (dh <= 12) ? bwd_blocks(n_tiles, heads / 4) : bwd_blocks(n_chunks, heads);
+    return blocks * 4 * sizeof(float) + 256;
 }
 
 int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,

@@ -1,12 +1,12 @@
-// a19-a21 for narrow heads (dh = 6, 12: SWFormer stages 1-2, C = 48 / 96): exact-fp32 vector-ALU window attention.
+// a19-a21 BACKWARD for the narrowest heads (dh = 6: SWFormer stage 1, C = 48): exact-fp32 vector-ALU window attention.
+// (The forward at every head width, and the backward at dh >= 12, run on the fused MFMA kernels: attention_fused*.hip.)
 //
-// At these stages the windows hold 13-60 voxels on average and a head is 6 or 12 channels wide: a 16x16x32 MFMA
-// tile would be 3/4 (dh = 6) or 5/8 (dh = 12) padding, and the matrix-core path spends its time on one dependent
-// chain of small loads per (32-token tile, head) wave.  Here one thread owns one (token, head) pair and keeps its
+// At this stage the windows hold ~15 voxels on average and a head is 6 channels wide: a 16x16x32 MFMA tile would be
+// 3/4 padding, and the matrix-core backward loses to this form (475 vs 360 us per layer on the headline scene).
+// Here one thread owns one (token, head) pair and keeps its
 // whole dh-vector in registers; the streamed side of a window (keys / queries) goes through LDS 32 tokens at a time,
 // every LDS read is a broadcast (all lanes of a half-wave share the head), nothing crosses lanes, and the
 // arithmetic is plain fp32 -- no operand split, no prepare pass, no workspace.
-//   forward : thread (query i, head h): scores of 32 keys in registers, online softmax, o += p * v
 //   pass Q  : thread (query i, head h): dq_hat += ds * k_hat / tau, dtau += ds * s          (ds = p (dp - delta))
 //   pass KV : thread (key j, head h)  : dv += p * dO, dk_hat += ds * q_hat / tau
 // with the gradient through x_hat = x / max(|x|, eps) applied to the thread's own vector at the end.
@@ -113,88 +113,6 @@ __device__ __forceinline__ void through_normalise(const Vec<DH>& x_raw, Vec<DH>*
 constexpr int kTile = 32;
 
 // ------------------------------------------------------------------ forward
-template <int DH>
-__global__ __launch_bounds__(256, 5) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int ldq, int ldk, int ldv,
-                                                      const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
-                                                      const int32_t* __restrict__ win_count, const int2* __restrict__ tile_item,
-                                                      int heads, const float* __restrict__ tau, float tau_min,
-                                                      float* __restrict__ out, float* __restrict__ lse) {
-    extern __shared__ float smem[];  // k_hat [32][heads*DH], v [32][heads*DH]
-    const int c = heads * DH;
-    float* kbuf = smem;
-    float* vbuf = smem + kTile * c;
-    const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
-    const int2 item = tile_item[blockIdx.x];
-    const int n = win_count[item.x], start = win_start[item.x];
-    const int qi = item.y * kTile + i;
-    const int32_t qtok = qi < n ? tok[start + qi] : -1;
-    Vec<DH> qn = zero_vec<DH>();
-    if (qtok >= 0) {
-        qn = load_vec<DH>(q + (int64_t)qtok * ldq + h * DH);
-        normalise<DH>(&qn, kLog2e / fmaxf(tau[0], tau_min));
-    }
-    float m_run = -INFINITY, l_run = 0.f;
-    Vec<DH> o = zero_vec<DH>();
-
-    // raw k / v rows of the tile to come are fetched while the current tile is multiplied
-    Vec<DH> k_next, v_next;
-    auto fetch_kv = [&](int t0) {
-        const int kj = t0 + i;
-        k_next = v_next = zero_vec<DH>();
-        if (kj < n) {
-            const int32_t kt = tok[start + kj];
-            k_next = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
-            v_next = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
-        }
-    };
-    fetch_kv(0);
-    for (int t0 = 0; t0 < n; t0 += kTile) {
-        __syncthreads();
-        {  // stage key row t0 + i, head h
-            Vec<DH> kk = k_next;
-            normalise<DH>(&kk, 1.0f);
-            store_vec<DH>(kbuf + i * c + h * DH, kk);
-            store_vec<DH>(vbuf + i * c + h * DH, v_next);
-        }
-        __syncthreads();
-        if (t0 + kTile < n) fetch_kv(t0 + kTile);
-        const int nk = n - t0 < kTile ? n - t0 : kTile;
-        // online softmax in groups of 8 keys (keeps the register footprint at 8 scores)
-#pragma unroll 1
-        for (int j0 = 0; j0 < kTile; j0 += 8) {
-            if (j0 >= nk) break;
-            float s[8];
-            float gmax = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const Vec<DH> kk = load_vec<DH>(kbuf + (j0 + j) * c + h * DH);
-                s[j] = j0 + j < nk ? dot(qn, kk) : -INFINITY;
-                gmax = fmaxf(gmax, s[j]);
-            }
-            const float m_new = fmaxf(m_run, gmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float psum = 0.f;
-            scale<DH>(alpha, &o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(s[j] - m_new);
-                psum += p;
-                const Vec<DH> vv = load_vec<DH>(vbuf + (j0 + j) * c + h * DH);
-                axpy<DH>(p, vv, &o);
-            }
-            l_run = fmaf(l_run, alpha, psum);
-            m_run = m_new;
-        }
-    }
-    if (qtok >= 0) {
-        scale<DH>(1.0f / l_run, &o);
-        store_vec<DH>(out + (int64_t)qtok * c + h * DH, o);
-        if (lse) lse[(int64_t)qtok * heads + h] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
-    }
-}
-
-// ------------------------------------------------------------------ backward, pass Q: dq, dtau
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, int ldq, int ldk, int ldv,
@@ -381,17 +299,6 @@ __global__ __launch_bounds__(1024) void tau_reduce_small(const float* __restrict
 }
 
 template <int DH>
-int run_small_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
-                  const int32_t* win_start, const int32_t* win_count, const int2* tile_item, int n_tiles, int heads,
-                  const float* tau, float tau_min, float* out, float* lse, hipStream_t st) {
-    const size_t smem = (size_t)2 * kTile * heads * DH * sizeof(float);
-    hipLaunchKernelGGL(attn_small_fwd<DH>, dim3((unsigned)n_tiles), dim3(32 * heads), smem, st, q, k, v, ldq, ldk, ldv, tok,
-                       win_start, win_count, tile_item, heads, tau, tau_min, out, lse);
-    SEG3D_CHECK_LAUNCH();
-    return SEG3D_OK;
-}
-
-template <int DH>
 int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                   const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                   const int32_t* win_count, const int2* tile_item, int n_tiles, int heads, const float* tau, float tau_min,
@@ -412,28 +319,17 @@ int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int l
 
 }  // namespace
 
-// used by seg3d_window_attn_fwd / _bwd (attention_mfma.hip, attention_bwd.hip); heads <= 8, dh in {6, 12}
-bool attn_small_supported(int heads, int dh) { return (dh == 6 || dh == 12) && heads >= 1 && heads <= 8; }
-
-int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
-                          const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles,
-                          int heads, int dh, const float* tau, float tau_min, float* out, float* lse, hipStream_t st) {
-    const int2* ti = reinterpret_cast<const int2*>(tile_item);
-    if (dh == 6)
-        return run_small_fwd<6>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, ti, n_tiles, heads, tau, tau_min, out, lse, st);
-    return run_small_fwd<12>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, ti, n_tiles, heads, tau, tau_min, out, lse, st);
-}
+// used by seg3d_window_attn_bwd (attention.hip): dh 6, up to 8 heads
+bool attn_small_supported(int heads, int dh) { return dh == 6 && heads >= 1 && heads <= 8; }
 
 int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                           const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads, int dh,
                           const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
                           float* dtau, void* workspace, const DropoutParams& drop, hipStream_t st) {
+    if (dh != 6) return SEG3D_EINVAL;
     const int2* ti = reinterpret_cast<const int2*>(tile_item);
     float* tau_part = static_cast<float*>(workspace);  // n_tiles floats
-    if (dh == 6)
-        return run_small_bwd<6>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
-                                tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st);
-    return run_small_bwd<12>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
-                             tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st);
+    return run_small_bwd<6>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
+                            tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st);
 }

@@ -1257,6 +1257,11 @@ def window_attention_packed(qk, v, tau, tau_min, heads, wi, drop_p=0.0, drop_see
     if qk.dtype != torch.float32 or v.dtype != torch.float32 or not qk.is_contiguous() or not v.is_contiguous() \
             or qk.shape[1] != 2 * v.shape[1]:
         raise _lib.Seg3dError("qk must be contiguous float32 [m, 2C] and v contiguous float32 [m, C]")
+    if v.shape[1] % heads or not _lib.load().seg3d_window_attn_supported(int(heads), v.shape[1] // int(heads)):
+        raise _lib.Seg3dError(
+            f"window attention: {heads} heads on {v.shape[1]} channels is not a head geometry of this path (head widths "
+            "6 / 12 with a head count that is a multiple of 4, 24 / 48 with up to 16 heads; the reference builds 8 heads "
+            "on 48 / 96 / 192 / 384 channels, pointtransformer.py:143-155)")
     return _WindowAttnPackedFn.apply(qk, v, tau, tau_min, heads, wi, float(drop_p), int(drop_seed))
 
 

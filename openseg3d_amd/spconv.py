@@ -241,6 +241,14 @@ class SparseSequential(SparseModule):
         for i, m in enumerate(mods):
             self.add_module(str(i), m)
 
+    def __getitem__(self, idx):  # (spconv's SparseSequential is indexable like nn.Sequential)
+        if not -len(self) <= idx < len(self):
+            raise IndexError(f"index {idx} is out of range")
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
     def forward(self, x):
         for m in self._modules.values():
             if isinstance(m, SparseModule):

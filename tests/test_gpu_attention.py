@@ -169,3 +169,18 @@ def test_attention_dropout_statistics(dev, windows):
     f = dropout_factors(0.1, 11, big, 0, counts[big]) == 0.0
     both = float((f[:, 0::2][:, : f.shape[1] // 2] & f[:, 1::2][:, : f.shape[1] // 2]).mean())
     assert abs(both - (26.0 / 256.0) ** 2) < 0.004
+
+
+def test_unsupported_head_geometry_is_refused_with_a_clear_error(dev, windows):
+    """The kernels take the reference's head geometries (8 heads of 6 / 12 / 24 / 48 channels, pointtransformer.py:143-155)
+    and their obvious relatives; anything else is refused up front -- by name, not by a bare SEG3D_EINVAL from the launch
+    -- and seg3d_window_attn_supported tells a caller beforehand."""
+    from openseg3d_amd import _lib, ops
+    lib = _lib.load()
+    for heads, dh, ok in ((8, 6, 1), (8, 12, 1), (8, 24, 1), (8, 48, 1), (4, 12, 1), (16, 24, 1), (3, 12, 0), (6, 6, 0),
+                          (8, 32, 0), (12, 6, 0), (17, 24, 0)):
+        assert lib.seg3d_window_attn_supported(heads, dh) == ok, (heads, dh)
+    wi, m = windows
+    qk, v = torch.randn(m, 72, device=dev), torch.randn(m, 36, device=dev)
+    with pytest.raises(_lib.Seg3dError, match="head geometry"):
+        ops.window_attention_packed(qk, v, torch.ones(1, 1, 1, device=dev), 0.01, 3, wi)

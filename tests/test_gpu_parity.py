@@ -391,6 +391,31 @@ def test_swformer_block_matches_reference(dev, golden_dir, name):
     assert float(np.abs(_np(y) - d[name + "_out"]).max()) < 3e-4
 
 
+def test_config1_uniform_voxels_block_matches_reference(dev, golden_dir):
+    """BASELINE configs[0] / SURVEY 8(d) Config 1: 4 000 uniformly random voxels in a 400 x 400 x 20 grid, C = 48, 8 heads,
+    window (10, 10, 8) -- 2 637 windows of 1-6 tokens, 1 638 of them a single token (every tile almost empty, every
+    softmax over one to six keys).  SWFormerBlock(depth 2) and the first layer's attention vs the reference's own module
+    outputs (tests/golden/config1_block.npz, make_golden.gen_config1); window ids of both shifts bit-exact."""
+    from oracle import params
+    from openseg3d_amd.swformer import SparseWindowPartitionLayer, SWFormerBlock
+    d = np.load(os.path.join(golden_dir, "config1_block.npz"))
+    c, depth, seed, sx, sy, sz = (int(v) for v in d["meta"])
+    blk = SWFormerBlock(c, 8, depth=depth, drop_path=[0.1] * depth)
+    params.fill_by_name(blk, seed=seed)
+    blk = blk.to(dev).eval()
+    part = SparseWindowPartitionLayer(refcfg.BATCHING_INFO[0], refcfg.WINDOW_SHAPE, [float(sx), float(sy), float(sz)])
+    coords = torch.from_numpy(d["coords"]).to(dev)
+    plan = part.plan(coords, 1, c, want_debug=True)
+    for s in range(2):
+        assert np.array_equal(_np(plan.index[s].win_id).astype(np.int64), d[f"win{s}"])
+    feats = torch.from_numpy(d["feats"]).to(dev)
+    with torch.no_grad():
+        a0 = blk.layers[0].win_attn(feats, plan.pos[0], plan.index[0])
+        y = blk({"voxel_features": feats, "plan": plan})
+    assert float(np.abs(_np(a0) - d["attn0"]).max()) < 2e-4
+    assert float(np.abs(_np(y) - d["out"]).max()) < 3e-4
+
+
 def test_window_attention_backward_vs_oracle_autograd(dev, golden_dir):
     from oracle import params, window as W
     d, blk, plan, st, c, depth, seed = _load_block(dev, golden_dir, "c48")

@@ -77,6 +77,23 @@ def test_swformer_block_matches_reference(golden_dir, name):
     assert float((a0 - torch.from_numpy(d[name + "_attn0"])).abs().max()) <= 1e-5
 
 
+def test_config1_uniform_voxels_block_matches_reference(golden_dir):
+    """BASELINE configs[0] (4 000 uniform voxels in 400 x 400 x 20, C = 48, window (10, 10, 8)): windows of
+    1-6 tokens, 62 % of them a single token -- the reference's SWFormerBlock output vs the oracle."""
+    d = np.load(os.path.join(golden_dir, "config1_block.npz"))
+    c, depth, seed, sx, sy, sz = (int(v) for v in d["meta"])
+    coords, feats = torch.from_numpy(d["coords"]), torch.from_numpy(d["feats"])
+    info = W.window_partition(coords, refcfg.BATCHING_INFO[0], refcfg.WINDOW_SHAPE, np.array([sx, sy, sz], dtype=np.float64), c)
+    assert np.array_equal(info["batch_win_inds_shift0"].numpy(), d["win0"])
+    assert np.array_equal(info["batch_win_inds_shift1"].numpy(), d["win1"])
+    p = params.state_dict_for(refcfg.swformer_param_shapes(c, depth), seed)
+    y = W.swformer_block(feats, info, p, "", depth, 8)
+    a0 = W.window_attention(feats, info["pos_dict_shift0"], info["flat2win_inds_shift0"], info["key_mask_shift0"], p,
+                            "layers.0.win_attn.", 8)
+    assert float((y - torch.from_numpy(d["out"])).abs().max()) <= 1e-5
+    assert float((a0 - torch.from_numpy(d["attn0"])).abs().max()) <= 1e-5
+
+
 def test_cosine_msa_matches_reference(golden_dir):
     d = np.load(os.path.join(golden_dir, "cosine_msa.npz"))
     t, w, c, h, seed = (int(v) for v in d["meta"])
