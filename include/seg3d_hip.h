@@ -387,6 +387,23 @@ int seg3d_segment_reduce_bwd(const float* dout, int32_t c, const int32_t* seg_of
                              const int32_t* offsets, const int32_t* argmax, int64_t n_seg,
                              int32_t mode, float* dx, void* stream);
 
+/* SURVEY 8(f) rank 1  DeepFusionBlock's cross attention over the kNN rows -- seg3d/models/layers/deep_fusion.py:26-45:
+ *     out_i = sum_j dropout(nan_to_num(softmax_j(<q_i, k_{idx[i][j]}> * scale, -inf where invalid[idx[i][j]]))) . v_{idx[i][j]}
+ * q [n, d], k / v [n_src, d], idx int32 [n, n_neighbors] (rows of k / v), d = 32, n_neighbors <= 16, scale = 1 / sqrt(d).
+ * invalid uint8 [n_src] (1 = the source row has no image feature: torch.sum(image_features, 1) == 0) or NULL;
+ * keep float [n, n_neighbors] = the dropout factors F.dropout would multiply with (0 or 1 / (1 - p)) or NULL;
+ * prob [n, n_neighbors] receives the softmax (before dropout) for the backward, may be NULL.  Nothing of size
+ * [n, n_neighbors, d] is materialised.  Backward: dq, and dk / dv by a fixed-order sum over the inverse neighbour
+ * lists -- pair_order / pair_offsets = seg3d_group_index of the flattened idx table over the n_src rows -- so it is
+ * free of float atomics and bit-reproducible; scratch holds 2 * n * n_neighbors floats. */
+int seg3d_knn_attention_fwd(const float* q, const float* k, const float* v, const int32_t* idx,
+                            const uint8_t* invalid, const float* keep, int64_t n, int64_t n_src,
+                            int32_t n_neighbors, int32_t d, float scale, float* out, float* prob, void* stream);
+int seg3d_knn_attention_bwd(const float* q, const float* k, const float* v, const int32_t* idx, const float* keep,
+                            const float* prob, const float* dout, const int32_t* pair_order,
+                            const int32_t* pair_offsets, int64_t n, int64_t n_src, int32_t n_neighbors, int32_t d,
+                            float scale, float* dq, float* dk, float* dv, float* scratch, void* stream);
+
 /* a24  VoxelToPoint.__call__ -- seg3d/ops/voxel_to_point/voxel_to_point.py:4-17
  * out[i] = feats[ids[i]] (zeros where ids[i] == -1).  Its backward is
  * seg3d_segment_reduce_fwd(dout, SUM) over the CSR of ids. */

@@ -1585,6 +1585,55 @@ def knn_query(nsample, xyz, new_xyz, offset, new_offset, levels=None):
     return idx, torch.sqrt(d2)
 
 
+class _KnnAttentionFn(torch.autograd.Function):
+    """DeepFusionBlock's attention over the kNN rows (deep_fusion.py:31-43) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, idx, invalid, keep, scale):
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        n, d = q.shape
+        kk = idx.shape[1]
+        out = torch.empty((n, d), dtype=torch.float32, device=q.device)
+        need = any(ctx.needs_input_grad[:3])
+        prob = torch.empty((n, kk), dtype=torch.float32, device=q.device) if need else None
+        _lib.call("seg3d_knn_attention_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(idx), _ptr(invalid), _ptr(keep), n, k.shape[0], kk, d,
+                  float(scale), _ptr(out), _ptr(prob), _stream())
+        if need:
+            ctx.save_for_backward(q, k, v, idx, keep, prob)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, idx, keep, prob = ctx.saved_tensors
+        dout = _f32c(dout)
+        n, d = q.shape
+        kk, n_src = idx.shape[1], k.shape[0]
+        # inverse neighbour lists: pairs (i, j) grouped by the source row they read, ascending pair index inside a row
+        _, order, offsets = group_index(idx.reshape(-1), n_src, rank=False)
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        dv = torch.empty_like(v)
+        scratch = torch.empty((2 * n * kk,), dtype=torch.float32, device=q.device)
+        _lib.call("seg3d_knn_attention_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(idx), _ptr(keep), _ptr(prob), _ptr(dout),
+                  _ptr(order), _ptr(offsets), n, n_src, kk, d, float(ctx.scale), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch),
+                  _stream())
+        return dq, dk, dv, None, None, None, None
+
+
+def knn_attention(q, k, v, idx, invalid=None, keep=None, scale=None):
+    """out_i = sum_j dropout(nan_to_num(softmax_j(<q_i, k[idx_ij]> * scale, masked where invalid[idx_ij]))) * v[idx_ij]
+    (seg3d/models/layers/deep_fusion.py:31-43) without the [n, K, d] gathers.  q [n, 32], k / v [n_src, 32] float32,
+    idx int32 [n, K <= 16]; invalid: bool / uint8 [n_src] or None; keep: float32 [n, K] dropout factors or None."""
+    _need_gpu(q, k, v, idx)
+    if q.shape[1] != 32 or k.shape[1] != 32 or v.shape[1] != 32 or idx.dim() != 2 or idx.shape[1] > 16:
+        raise _lib.Seg3dError("knn_attention: 32 channels and at most 16 neighbours (DeepFusionBlock, segformer.py:51-53)")
+    idx = _i32c(idx)
+    inv = None if invalid is None else invalid.to(torch.uint8).contiguous()
+    kp = None if keep is None else _f32c(keep)
+    return _KnnAttentionFn.apply(q, k, v, idx, inv, kp, (q.shape[1] ** -0.5) if scale is None else float(scale))
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f): labels
 def prepare_voxel_labels(point_voxel_ids, point_labels, n_voxels, ignore_index=255, cur_point_indices=None):
     """``WaymoDataset.prepare_voxel_labels`` (waymo_dataset.py:213-246) on the device: uint8 [n_voxels], the most

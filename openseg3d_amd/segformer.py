@@ -291,18 +291,30 @@ class DeepFusionBlock(nn.Module):
         self.attn_dropout = nn.Dropout(attn_pdrop)
         self.c_proj = nn.Linear(hidden_channel, image_channel)
 
-    def forward(self, points, point_id_offset, lidar_features, image_features):
+    def neighbours(self, points, point_id_offset):
+        """int32 [N, k] rows of the k nearest current-sweep points (deep_fusion.py:31).  Depends on the points alone: the
+        batch builder / input pipeline may compute it ahead of the forward (Segformer.prepare_batch)."""
+        xyz = points.contiguous() if self.faithful_stride else points[:, :3].contiguous()
+        knn_ids, _ = ops.knn_query(self.n_neighbors, xyz, xyz, point_id_offset, point_id_offset)
+        return knn_ids
+
+    def forward(self, points, point_id_offset, lidar_features, image_features, knn_ids=None):
         q = self.q_embedding(lidar_features)
         k = self.k_embedding(image_features)
         v = self.v_embedding(image_features)
-        xyz = points.contiguous() if self.faithful_stride else points[:, :3].contiguous()
-        knn_ids, _ = ops.knn_query(self.n_neighbors, xyz, xyz, point_id_offset, point_id_offset)
+        if knn_ids is None:
+            knn_ids = self.neighbours(points, point_id_offset)
+        invalid = image_features.sum(dim=1) == 0
+        if q.is_cuda and q.shape[1] == 32 and self.n_neighbors <= 16:
+            # one kernel each way: dot products, masked softmax, dropout factors and the weighted sum over the 16 neighbour
+            # rows, nothing of size [N, 16, 32] materialised (seg3d_knn_attention_fwd / _bwd)
+            keep = None
+            if self.training and self.attn_dropout.p > 0.0:  # F.dropout's factors, drawn by torch as the reference does
+                keep = self.attn_dropout(torch.ones(knn_ids.shape, dtype=torch.float32, device=q.device))
+            return self.c_proj(ops.knn_attention(q, k, v, knn_ids, invalid, keep))
         knn_ids = knn_ids.long()
-        # per-point dot products with 16 gathered rows: broadcast multiply + reduce (HBM-bound, ~0.3 ms on 233 k points);
-        # the einsum form goes to rocBLAS batched GEMM with 1 x 32 x 16 problems (3.7 ms per call, 22 ms per step)
         attn = (q.unsqueeze(1) * k[knn_ids]).sum(dim=-1) / (q.shape[-1] ** 0.5)
-        invalid = (image_features.sum(dim=1) == 0)[knn_ids]
-        attn = attn.masked_fill(invalid, float("-inf"))
+        attn = attn.masked_fill(invalid[knn_ids], float("-inf"))
         attn = torch.nan_to_num(torch.softmax(attn, dim=-1))
         attn = self.attn_dropout(attn)
         return self.c_proj((attn.unsqueeze(-1) * v[knn_ids]).sum(dim=1))
@@ -355,7 +367,22 @@ class Segformer(nn.Module):
         input pipeline calls this for batch i+1 on its own stream while batch i trains (bench.py)."""
         if "site_level" not in batch_dict:
             self.point_transformer.prepare(batch_dict)
+        if self.use_image_feature and "fusion_knn" not in batch_dict:
+            # DeepFusionBlock's neighbour search reads the points only (13 ms of a 63 ms multi-sweep forward): part of the plan
+            cur_points, _ = self._current_sweep(batch_dict)
+            batch_dict["fusion_knn"] = self.deep_fusion.neighbours(cur_points, batch_dict["point_id_offset"].int())
         return batch_dict
+
+    def _current_sweep(self, batch_dict):
+        """(rows of the current sweep without the batch column, their row numbers or None) -- segformer.py:96-100; the row
+        numbers are found once per batch (torch.nonzero reads a count back) and travel with it."""
+        points = batch_dict["points"][:, 1:]
+        if not self.use_multi_sweeps:
+            return points, None
+        cur_rows = batch_dict.get("cur_rows")
+        if cur_rows is None:
+            cur_rows = batch_dict["cur_rows"] = torch.nonzero(points[:, 3] == 0).view(-1)  # time lag column == 0
+        return points[cur_rows], cur_rows
 
     def forward(self, batch_dict):
         if self.training and torch.is_grad_enabled():
@@ -376,14 +403,24 @@ class Segformer(nn.Module):
             self.point_transformer.prepare(batch_dict)
 
         if self.use_multi_sweeps:
-            cur = points[:, 3] == 0  # rows of the current sweep: time lag column == 0 (segformer.py:98)
-            cur_rows = torch.nonzero(cur).view(-1)
-            cur_points = points[cur_rows]
+            cur_points, cur_rows = self._current_sweep(batch_dict)  # rows whose time lag column == 0 (segformer.py:98)
             cur_ids = seg.ids[cur_rows]
             cur_seg = None
             batch_rows = batch_dict["points"][cur_rows, 0]
         else:
             cur_points, cur_ids, cur_seg, batch_rows = points, seg.ids, seg, batch_dict["points"][:, 0]
+        knn_ids, knn_done = batch_dict.get("fusion_knn"), None
+        if self.use_image_feature and knn_ids is None and points.is_cuda:
+            # not planned ahead: the search depends on the points alone, so it runs on the second stream beside the point
+            # encoder and the whole backbone and is awaited where DeepFusion needs it
+            main, side = torch.cuda.current_stream(points.device), ops.side_stream(points.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                knn_ids = self.deep_fusion.neighbours(cur_points, batch_dict["point_id_offset"].int())
+                knn_done = torch.cuda.Event()
+                knn_done.record(side)
+            knn_ids.record_stream(main)
+            cur_points.record_stream(side)
         point_features = self.point_encoder(cur_points)
 
         batch_dict["voxel_features"] = self.vfe(points if self.use_multi_sweeps else point_features, seg)
@@ -392,8 +429,10 @@ class Segformer(nn.Module):
         point_voxel_features = ops.gather_rows(batch_dict["voxel_features"], cur_ids, cur_seg)
         fused = torch.cat([point_features, point_voxel_features], dim=1)
         if self.use_image_feature:
+            if knn_done is not None:
+                torch.cuda.current_stream(points.device).wait_event(knn_done)
             img = self.deep_fusion(cur_points, batch_dict["point_id_offset"].int(), fused,
-                                   batch_dict["point_image_features"])
+                                   batch_dict["point_image_features"], knn_ids)
             fused = torch.cat([fused, img], dim=1)
         fused = self.fusion_encoder(fused)
 

@@ -704,3 +704,47 @@ def test_aux_voxel_labels_take_the_nearest_fine_voxel(dev):
         d = fc[same] - cc[i]
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         assert got[i] == labels[same[np.argmin(d2)]] or np.sum(d2 == d2.min()) > 1
+
+
+@pytest.mark.parametrize("kk,drop", [(16, False), (16, True), (5, False)])
+def test_knn_attention_matches_the_reference_composition(dev, kk, drop):
+    """DeepFusionBlock's attention over the kNN rows (seg3d/models/layers/deep_fusion.py:31-43: gather k / v by the
+    neighbour table, einsum, -inf mask where the neighbour has no image feature, softmax, nan_to_num, dropout, einsum) as
+    one kernel each way (seg3d_knn_attention_fwd / _bwd) against that composition in fp64 autograd: forward and the
+    gradients w.r.t. q, k, v; rows whose neighbours are all masked give 0 and pass no gradient; the backward's
+    fixed-order sums make it bit-reproducible."""
+    from openseg3d_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    n, n_src, d = 3001, 2500, 32
+    q = torch.randn(n, d, generator=gen)
+    k = torch.randn(n_src, d, generator=gen)
+    v = torch.randn(n_src, d, generator=gen)
+    idx = torch.randint(0, n_src, (n, kk), generator=gen, dtype=torch.int32)
+    invalid = torch.rand(n_src, generator=gen) < 0.3
+    idx[7] = torch.nonzero(invalid)[:kk, 0].to(torch.int32)  # a query whose neighbours are ALL masked
+    idx[8, 1:] = idx[8, 0]                                    # duplicates in a neighbour list
+    keep = ((torch.rand(n, kk, generator=gen) >= 0.3).float() / 0.7) if drop else None
+    g = torch.randn(n, d, generator=gen)
+
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    li = idx.long()
+    attn = torch.einsum("nc,nkc->nk", qr, kr[li]) / d ** 0.5
+    attn = attn.masked_fill(invalid[li], float("-inf"))
+    attn = torch.nan_to_num(torch.softmax(attn, dim=-1))
+    if keep is not None:
+        attn = attn * keep.double()
+    ref = torch.einsum("nk,nkc->nc", attn, vr[li])
+    ref.backward(g.double())
+
+    qg, kg, vg = (t.to(dev).requires_grad_() for t in (q, k, v))
+    out = ops.knn_attention(qg, kg, vg, idx.to(dev), invalid.to(dev), None if keep is None else keep.to(dev))
+    out.backward(g.to(dev))
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 2e-5
+    assert float(out[7].abs().max()) == 0.0
+    for name, got, want in (("dq", qg.grad, qr.grad), ("dk", kg.grad, kr.grad), ("dv", vg.grad, vr.grad)):
+        assert float((got.cpu().double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max())), name
+    first = [t.grad.clone() for t in (qg, kg, vg)]
+    for t in (qg, kg, vg):
+        t.grad = None
+    ops.knn_attention(qg, kg, vg, idx.to(dev), invalid.to(dev), None if keep is None else keep.to(dev)).backward(g.to(dev))
+    assert all(torch.equal(a, t.grad) for a, t in zip(first, (qg, kg, vg)))
