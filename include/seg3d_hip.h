@@ -172,6 +172,15 @@ int seg3d_spconv_fwd_act(const float* x, const int32_t* nbr, int64_t m_out, int6
                          int32_t pack_flags, const float* bias /*or NULL*/, const float* addend /*or NULL*/,
                          int32_t relu, int32_t cin, int32_t cout, float* y, const int32_t* row_order /*or NULL*/,
                          void* stream);
+/* The same block with the sparse-conv feature maps STORED in bf16 (opt-in storage mode, BASELINE configs[4]; the
+ * reference's only reduced-precision hook is seg3d/ops/voxel_pooling/voxel_pooling.py:12): x holds float32 (x_bf16 = 0)
+ * or bf16 (x_bf16 = 1) rows, y and the residual addend are bf16 [m_out, cout]; accumulation, bias and activation stay
+ * float32, the weights stay split-bf16 hi + lo.  A bf16 row is its own hi part: its products take two MFMAs instead of
+ * three and its gather moves half the bytes.  Inference only (no backward entry point takes bf16 rows). */
+int seg3d_spconv_fwd_act_bf16(const void* x, int32_t x_bf16, const int32_t* nbr, int64_t m_out, int64_t m_in,
+                              const void* w_packed, int32_t pack_flags, const float* bias,
+                              const void* addend_bf16, int32_t relu, int32_t cin, int32_t cout, void* y_bf16,
+                              const int32_t* row_order, void* stream);
 /* Wide layers (cin >= 192): the same contract as seg3d_spconv_fwd_act with the operand conversion hoisted out of the
  * gather-GEMM.  seg3d_spconv_presplit writes x [m_in, cin] once as bf16 hi plane | lo plane ([m_in + 1, cin] each; the
  * extra row is zero and stands for every inactive table entry) into xs (seg3d_spconv_presplit_bytes);

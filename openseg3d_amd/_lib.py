@@ -40,6 +40,7 @@ SIGNATURES = {
     "seg3d_spconv_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_spconv_fwd": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_spconv_fwd_act": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    "seg3d_spconv_fwd_act_bf16": (ctypes.c_int, [_p, _i32, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "seg3d_spconv_presplit_bytes": (_sz, [_i64, _i32]),
     "seg3d_spconv_presplit": (ctypes.c_int, [_p, _i64, _i32, _p, _p]),
     "seg3d_spconv_fwd_presplit": (ctypes.c_int, [_p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),

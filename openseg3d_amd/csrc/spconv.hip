@@ -16,6 +16,9 @@
 size_t spconv_split_packed_bytes(int cin_op, int cout_op, int kk);
 int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transpose, int flip, void* w_packed,
                       hipStream_t st);
+int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                        const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
+                        hipStream_t st);
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st);
 size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
@@ -331,6 +334,22 @@ int seg3d_spconv_fwd_act(const float* x, const int32_t* nbr, int64_t m_out, int6
     if (m_out == 0) return SEG3D_OK;
     if (!x || !nbr || !y) return SEG3D_EINVAL;
     return spconv_split_fwd(x, nbr, m_out, w_packed_v, bias, addend, row_order, cin, cout, y, relu ? 1 : 0, as_stream(stream));
+}
+
+/* The same block with the feature maps STORED in bf16 (opt-in, BASELINE configs[4]; the reference's only reduced-
+ * precision hook is voxel_pooling.py:12): x is float32 (x_bf16 = 0) or bf16 (x_bf16 = 1) rows, y and the residual addend
+ * are bf16; accumulation, bias and activation stay float32.  A bf16 row is its own hi part, so its products take two
+ * MFMAs instead of three and its gather moves half the bytes. */
+int seg3d_spconv_fwd_act_bf16(const void* x, int32_t x_bf16, const int32_t* nbr, int64_t m_out, int64_t m_in,
+                              const void* w_packed_v, int32_t pack_flags, const float* bias, const void* addend_bf16,
+                              int32_t relu, int32_t cin, int32_t cout, void* y_bf16, const int32_t* row_order,
+                              void* stream) {
+    if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !w_packed_v || !(pack_flags & 4))
+        return SEG3D_EINVAL;
+    if (m_out == 0) return SEG3D_OK;
+    if (!x || !nbr || !y_bf16) return SEG3D_EINVAL;
+    return spconv_split_fwd_io(x, nbr, m_out, w_packed_v, bias, addend_bf16, row_order, cin, cout, y_bf16, relu ? 1 : 0,
+                               x_bf16 ? 2 : 1, as_stream(stream));
 }
 
 /* a6  exact-fp32 Linear (per-point MLPs): y[m, cout] = x[m, cin] . W^T + bias on v_mfma_f32_16x16x4_f32 -- the

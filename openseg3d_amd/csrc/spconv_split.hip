@@ -134,13 +134,21 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
     if (t < items) pack_item(jb.src, jb.cin_src, jb.cout_src, jb.kk, jb.transpose, jb.flip, t, jb.dst);
 }
 
-template <int NBT, int RB, bool DENSE>
-__global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
+// IO: storage of the activations.  0 = float32 in, float32 out (the default path); 1 = float32 in, bf16 out;
+// 2 = bf16 in, bf16 out (the opt-in bf16-storage mode of the sparse-conv feature maps, BASELINE configs[4]): a bf16 row
+// IS its own hi part (lo = 0), so the a_lo . w_hi product disappears -- two MFMAs per product instead of three -- and a
+// gathered row is half the bytes.  Residual addend and output share the output's storage type; accumulation, bias and
+// the activation stay float32.
+template <int NBT, int RB, bool DENSE, int IO = 0>
+__global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __restrict__ x_v, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
                                                               const float* __restrict__ bias,
-                                                              const float* __restrict__ addend,
+                                                              const void* __restrict__ addend_v,
                                                               const int32_t* __restrict__ row_order, int cin, int cout,
-                                                              float* __restrict__ y, int relu) {
+                                                              void* __restrict__ y_v, int relu) {
+    const float* __restrict__ x = static_cast<const float*>(x_v);
+    const float* __restrict__ addend = static_cast<const float*>(addend_v);
+    float* __restrict__ y = static_cast<float*>(y_v);
     constexpr int kW = 4;
     constexpr int kSlot = NBT * 128;  // uint4 per staged chunk (NBT x {hi, lo} x 64 lanes)
     constexpr int kPieces = NBT * 2;  // 1-KiB wave-instructions per chunk
@@ -244,9 +252,13 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             for (int rb = 0; rb < RB; ++rb) {
                 aval[rb] = on && in_range && idx[rb] >= 0;
                 const int64_t src_row = idx[rb] >= 0 ? idx[rb] : 0;
-                const f32x4* p = reinterpret_cast<const f32x4*>(x + src_row * cin + col);
-                areg[rb][0] = p[0];
-                areg[rb][1] = p[1];
+                if constexpr (IO == 2) {  // 8 bf16 = one 16-B piece
+                    areg[rb][0] = *reinterpret_cast<const f32x4*>(static_cast<const __bf16*>(x_v) + src_row * cin + col);
+                } else {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(x + src_row * cin + col);
+                    areg[rb][0] = p[0];
+                    areg[rb][1] = p[1];
+                }
             }
         };
         bf16x8 a_hi[RB], a_lo[RB];
@@ -254,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                split8(aval[rb] ? areg[rb][0] : z, aval[rb] ? areg[rb][1] : z, &a_hi[rb], &a_lo[rb]);
+                if constexpr (IO == 2) a_hi[rb] = __builtin_bit_cast(bf16x8, aval[rb] ? areg[rb][0] : z);
+                else split8(aval[rb] ? areg[rb][0] : z, aval[rb] ? areg[rb][1] : z, &a_hi[rb], &a_lo[rb]);
             }
         };
 
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, slot[(n * 2 + 1) * 64 + lane]);
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) {
-                        acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[rb], bh, acc[rb][n], 0, 0, 0);
+                        if constexpr (IO != 2) acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[rb], bh, acc[rb][n], 0, 0, 0);
                         acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rb], bl, acc[rb][n], 0, 0, 0);
                         acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rb], bh, acc[rb][n], 0, 0, 0);
                     }
@@ -341,6 +354,16 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
             const int64_t opos = row0 + rb * 16 + g * 4 + r;
             if (opos < m_out) {
                 const int64_t orow = row_order ? (int64_t)row_order[opos] : opos;
+                if constexpr (IO != 0) {  // bf16 storage of the output (and of the residual it is added to)
+                    __bf16* yb = static_cast<__bf16*>(y_v) + orow * cout + nb0 * 16 + c16;
+                    const __bf16* ab = addend_v ? static_cast<const __bf16*>(addend_v) + orow * cout + nb0 * 16 + c16 : nullptr;
+#pragma unroll
+                    for (int n = 0; n < NBT; ++n) {
+                        const float v = acc[rb][n][r] + (ab ? (float)ab[n * 16] : 0.0f);
+                        yb[n * 16] = (__bf16)(relu ? (v < 0.0f ? 0.0f : v) : v);
+                    }
+                    continue;
+                }
                 float* yr = y + orow * cout + nb0 * 16 + c16;
                 // y = act(x W^T + b (+ addend)): addend = a second gradient path, or the residual of a conv block whose
                 // BatchNorm was folded into W and b (eval); relu = that block's activation
@@ -373,9 +396,20 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const float* __res
 }
 
 template <int NBT, int RB>
-int launch_split(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const float* addend,
-                 const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
+int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const void* addend,
+                 const int32_t* row_order, int cin, int cout, void* y, int relu, int io, hipStream_t st) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
+    if (io == 1 || io == 2) {  // bf16-storage variants (sparse convs only)
+        if (nbr == nullptr) return SEG3D_EINVAL;
+        if (io == 1)
+            hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 1>), grid, dim3(256), 0, st, x, nbr, m_out,
+                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu);
+        else
+            hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 2>), grid, dim3(256), 0, st, x, nbr, m_out,
+                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu);
+        SEG3D_CHECK_LAUNCH();
+        return SEG3D_OK;
+    }
     if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
                            reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu);
@@ -416,8 +450,9 @@ extern "C" int seg3d_debug_set_conv_nbt(int32_t nbt) {
     return SEG3D_OK;
 }
 
-int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
+int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                        const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
+                        hipStream_t st) {
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deepest level has few rows
     // (19k) and 384+ columns: 128-column workgroups put it on the chip in ONE resident round (153 row tiles x 3 = 459 of
     // 512 slots; 96 columns = 612 = a second, mostly empty round) and gather each row 3 times instead of 4
@@ -432,14 +467,19 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
     else if (nb % 2 == 0) pick = 2;
     if (const int w = g_forced_nbt.load(std::memory_order_relaxed); w > 0 && nb % w == 0) pick = w;
     switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
-        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, st);
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
     }
+}
+
+int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                     const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
+    return spconv_split_fwd_io(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, 0, st);
 }
 
 // ------------------------------------------------------------------ dense Linear layers through the same kernel

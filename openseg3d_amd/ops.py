@@ -607,8 +607,33 @@ def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
     return y
 
 
+# Storage of the sparse-conv feature maps in INFERENCE: "fp32" (default: the path the 1e-3 logit bar is stated for) or "bf16"
+# (opt-in, BASELINE configs[4] names bf16; SEG3D_STORAGE=bf16 or bench.py --storage bf16).  Which tensors may be rounded was
+# decided per op family from tools/bf16_storage_probe.py (max |dlogit| at max |logit| 207 / arg-max changes, headline
+# scene): sparse-conv outputs 3.4e-2 / 0.02 %; attention 1.1e-2; voxel-path Linear 1.8e-2; the residual stream behind
+# the LayerNorms 1.95 / 0.44 %; the per-point MLPs 2.4 / 0.51 % -- so the mode covers the conv feature maps (the
+# gather-bound tensors of the dense configuration) and nothing else.
+STORAGE = os.environ.get("SEG3D_STORAGE", "fp32")
+
+
+def conv_storage_bf16():
+    if STORAGE not in ("fp32", "bf16"):
+        raise _lib.Seg3dError(f"SEG3D_STORAGE must be 'fp32' or 'bf16', got {STORAGE!r}")
+    return STORAGE == "bf16" and CONV_PRECISION == "bf16x3" and not torch.is_grad_enabled()
+
+
 def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True):
-    """act(conv(x) + bias (+ addend)) in one launch (inference form of a conv block, seg3d_spconv_fwd_act)."""
+    """act(conv(x) + bias (+ addend)) in one launch (inference form of a conv block, seg3d_spconv_fwd_act); in the bf16
+    storage mode the output (and the residual it adds) is bf16, the input float32 or bf16 as it comes."""
+    if conv_storage_bf16() and not _conv_dma_fits(packed, cin, cout):
+        xin = x.contiguous() if x.dtype in (torch.float32, torch.bfloat16) else x.float().contiguous()
+        m_out = nbr.shape[1]
+        y = torch.empty((m_out, cout), dtype=torch.bfloat16, device=x.device)
+        res = None if addend is None else addend.to(torch.bfloat16).contiguous()
+        _lib.call("seg3d_spconv_fwd_act_bf16", _ptr(xin), int(xin.dtype == torch.bfloat16), _ptr(nbr), m_out, xin.shape[0],
+                  _ptr(packed.data), packed.flags, _ptr(bias), _ptr(res), int(bool(relu)), cin, cout, _ptr(y), _ptr(order),
+                  _stream())
+        return y
     x = _f32c(x)
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)

@@ -260,6 +260,8 @@ class RowLinear(nn.Linear):
     """nn.Linear on [rows, C] activations whose weight gradient runs in libseg3d_hip.so (ops.linear)."""
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16:  # a sparse-conv feature map of the bf16 storage mode: arithmetic stays float32
+            x = x.float()
         return ops.linear(x, self.weight, self.bias, exact=True)
 
 

@@ -180,7 +180,7 @@ class _Conv3x3x3(SparseModule):
         """Inference only: conv -> BatchNorm(eval) -> (+ residual) -> ReLU can run as one launch."""
         return (FUSE_EVAL_BN and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and bn.affine
                 and not self._pad_in and ops.CONV_PRECISION == "bf16x3" and x.features.is_cuda
-                and x.features.dtype == torch.float32)
+                and (x.features.dtype == torch.float32 or (x.features.dtype == torch.bfloat16 and ops.conv_storage_bf16())))
 
     def forward_bn_act(self, x, bn, relu=True, res=None):
         """act(bn(conv(x)) (+ res)) with the BatchNorm's running-statistics affine folded into the packed weights and the

@@ -260,6 +260,8 @@ class SWFormerBlock(nn.Module):
 
     def forward(self, voxel_info):
         x, plan = voxel_info["voxel_features"], voxel_info["plan"]
+        if x.dtype == torch.bfloat16:  # a sparse-conv feature map of the bf16 storage mode: the residual stream is float32
+            x = x.float()
         half = int(self.depth / 2)  # first depth//2 layers on the unshifted windows (:321-337)
         scales = self.drop_path_scales(x) if self.training else None
         # one draw from the CPU generator per block and forward (no device round trip); layer i uses seed + i

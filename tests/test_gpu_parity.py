@@ -748,3 +748,36 @@ def test_knn_attention_matches_the_reference_composition(dev, kk, drop):
         t.grad = None
     ops.knn_attention(qg, kg, vg, idx.to(dev), invalid.to(dev), None if keep is None else keep.to(dev)).backward(g.to(dev))
     assert all(torch.equal(a, t.grad) for a, t in zip(first, (qg, kg, vg)))
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 48), (48, 96), (96, 96), (96, 192), (192, 128)])
+def test_bf16_storage_conv_matches_fp32_storage_conv(dev, golden_dir, monkeypatch, cin, cout):
+    """Opt-in bf16 storage of the sparse-conv feature maps (seg3d_spconv_fwd_act_bf16; BASELINE configs[4]).  The kernel
+    keeps fp32 accumulation, bias and activation: from float32 rows its output is the float32-storage output rounded to
+    bf16 (1 ulp); from bf16 rows (which are their own hi part: two MFMAs per product instead of three) it equals the
+    float32-storage kernel fed the same, exactly representable, rows; the residual is read as bf16.  Every column-block
+    width the launcher picks (3 / 6 / 12 / 8 blocks of 16 columns) on the golden scene's level-1 and level-2 sites."""
+    from openseg3d_amd import ops, spconv
+    coords, bs = _golden_coords(golden_dir)
+    lvl = spconv.SiteLevel(torch.from_numpy(coords).to(dev), refcfg.GRID_CART[::-1].tolist(), bs)
+    nbr = lvl.subm()
+    m = coords.shape[0]
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(m, cin, generator=gen).to(dev)
+    w = (torch.randn(cout, 3, 3, 3, cin, generator=gen) / (8 * cin) ** 0.5).to(dev)
+    bias = torch.randn(cout, generator=gen).to(dev)
+    res = torch.randn(m, cout, generator=gen).to(dev)
+    packed = ops.pack_weight(w, ops.PACK_FWD, use_registry=False)
+    with torch.no_grad():
+        for xin in (x, x.bfloat16()):
+            for addend, relu in ((None, False), (res, True)):
+                monkeypatch.setattr(ops, "STORAGE", "fp32")
+                ref = ops.conv_act(xin.float(), nbr, packed, bias, cin, cout, None,
+                                   None if addend is None else addend.bfloat16().float(), relu)
+                monkeypatch.setattr(ops, "STORAGE", "bf16")
+                got = ops.conv_act(xin, nbr, packed, bias, cin, cout, None, addend, relu)
+                assert got.dtype == torch.bfloat16 and ref.dtype == torch.float32
+                # one bf16 ulp of the float32-storage result (the two kernels sum the same products in the same order,
+                # minus the a_lo . w_hi terms that are exactly zero for bf16 rows)
+                ulp = ref.abs().clamp(min=1e-30) * 2.0 ** -8
+                assert bool(((got.float() - ref).abs() <= ulp + 1e-6).all()), (str(xin.dtype), relu)

@@ -565,3 +565,40 @@ def test_eval_forward_replays_from_a_hip_graph():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, eager)
+
+
+def test_bf16_storage_mode_stays_within_its_stated_tolerance(monkeypatch):
+    """The opt-in storage mode of BASELINE configs[4] (bench.py --storage bf16 / SEG3D_STORAGE=bf16): sparse-conv feature
+    maps stored in bf16 in the inference forward, everything else (accumulation, residual stream, attention, norms, point
+    MLPs) float32.  Its tolerance is stated against this build's own float32-storage forward: max |dlogit|
+    <= 5e-2 and arg-max agreement >= 99.5 % -- measured 1.3e-2 / 99.85 % with golden-style weights, 3.4e-2 / 99.98 % with
+    the default initialisation (tools/bf16_storage_probe.py).  The default path is untouched: switching the mode off
+    reproduces the float32-storage logits bit for bit."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import params
+    from openseg3d_amd import batch as B, config, ops, scene, segformer
+    dev = torch.device("cuda:0")
+    cfg = config.default_cfg()
+    ds = config.DatasetSpec(cfg)
+    pts = scene.make_scene(2)[::2]
+    for fill in (True, False):
+        torch.manual_seed(0)
+        model = segformer.build_segmentor(cfg, ds)
+        if fill:
+            params.fill_by_name(model, seed=0)
+        model = model.to(dev).eval()
+        b = B.make_batch([pts], ds.voxel_size, ds.point_cloud_range)
+        with torch.no_grad():
+            monkeypatch.setattr(ops, "STORAGE", "fp32")
+            ref = model(dict(b))["point_out"].clone()
+            monkeypatch.setattr(ops, "STORAGE", "bf16")
+            res = model(dict(b))
+            got = res["point_out"]
+            assert got.dtype == torch.float32 and res["voxel_out"].dtype == torch.float32
+            monkeypatch.setattr(ops, "STORAGE", "fp32")
+            again = model(dict(b))["point_out"]
+        err = float((got - ref).abs().max())
+        agree = float((got.argmax(1) == ref.argmax(1)).float().mean())
+        assert 0.0 < err <= 5e-2 and agree >= 0.995, (fill, err, agree)
+        assert torch.equal(again, ref)
