@@ -614,6 +614,7 @@ def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
 # the LayerNorms 1.95 / 0.44 %; the per-point MLPs 2.4 / 0.51 % -- so the mode covers the conv feature maps (the
 # gather-bound tensors of the dense configuration) and nothing else.
 STORAGE = os.environ.get("SEG3D_STORAGE", "fp32")
+STORAGE_ROUND_INPUTS = os.environ.get("SEG3D_STORAGE_ROUND_INPUTS", "1") != "0"
 
 
 def conv_storage_bf16():
@@ -626,7 +627,13 @@ def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True
     """act(conv(x) + bias (+ addend)) in one launch (inference form of a conv block, seg3d_spconv_fwd_act); in the bf16
     storage mode the output (and the residual it adds) is bf16, the input float32 or bf16 as it comes."""
     if conv_storage_bf16() and not _conv_dma_fits(packed, cin, cout):
-        xin = x.contiguous() if x.dtype in (torch.float32, torch.bfloat16) else x.float().contiguous()
+        # a float32 input (a SWFormer stage's output, the VFE rows, a concatenation) is rounded once here: the conv gathers
+        # every row ~7-17 times, so the one conversion pass is repaid by the halved gather (dense scene, 192 -> 96 @1.2 M
+        # rows: 2.9 -> 1.9 ms with bf16 rows); SEG3D_STORAGE_ROUND_INPUTS=0 keeps float32 inputs as they come
+        if x.dtype == torch.float32 and STORAGE_ROUND_INPUTS:
+            xin = x.to(torch.bfloat16).contiguous()
+        else:
+            xin = x.contiguous() if x.dtype in (torch.float32, torch.bfloat16) else x.float().contiguous()
         m_out = nbr.shape[1]
         y = torch.empty((m_out, cout), dtype=torch.bfloat16, device=x.device)
         res = None if addend is None else addend.to(torch.bfloat16).contiguous()

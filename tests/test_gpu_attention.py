@@ -184,3 +184,38 @@ def test_unsupported_head_geometry_is_refused_with_a_clear_error(dev, windows):
     qk, v = torch.randn(m, 72, device=dev), torch.randn(m, 36, device=dev)
     with pytest.raises(_lib.Seg3dError, match="head geometry"):
         ops.window_attention_packed(qk, v, torch.ones(1, 1, 1, device=dev), 0.01, 3, wi)
+
+
+def test_attention_time_does_not_depend_on_tau(dev):
+    """The forward has two softmax forms: the fixed-maximum one (every cosine score is bounded by log2e / tau) and, below
+    tau ~ 0.036 where that bound could underflow, the online-maximum one -- a wave-uniform branch on the device scalar.
+    A learnt temperature must not move a layer onto a slow path: on the headline scene's stage 1 (narrow heads) and
+    stage 3 (wide heads) the layer at tau = 0.02 takes at most 2x its time at tau = 1 (measured 1.1-1.2x; the round-2
+    record that read 11 ms for these layers was the instrumented pass allocating gigabytes of unused workspace)."""
+    from openseg3d_amd import batch as B, config, ops, scene, spconv, swformer
+    cfg = config.default_cfg()
+    ds = config.DatasetSpec(cfg)
+    b = B.make_batch([scene.make_scene(0)], ds.voxel_size, ds.point_cloud_range)
+    level = spconv.SiteLevel(b["voxel_coords"].int(), [int(g) for g in ds.grid_size][::-1], 1)
+    info = [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO]
+    for stage, c in enumerate((48, 96, 192)):
+        if stage != 1:
+            part = swformer.SparseWindowPartitionLayer(info[stage], cfg.MODEL.WINDOW_SHAPE, [float(g) / 2 ** stage for g in ds.grid_size])
+            wi = part.plan(level.coords, 1, c).index[0]
+            m = level.coords.shape[0]
+            qk, v = torch.randn(m, 2 * c, device=dev), torch.randn(m, c, device=dev)
+            times = {}
+            for tau_v in (1.0, 0.02):
+                tau = torch.full((1, 1, 1), tau_v, device=dev)
+                for _ in range(3):
+                    ops.window_attention_packed(qk, v, tau, 0.01, 8, wi)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    ops.window_attention_packed(qk, v, tau, 0.01, 8, wi)
+                e1.record()
+                torch.cuda.synchronize()
+                times[tau_v] = e0.elapsed_time(e1) / 10
+            assert times[0.02] <= 2.0 * times[1.0], (stage, times)
+        level = level.down()[0]
