@@ -351,6 +351,16 @@ def main():
         baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids))
         del o_res
 
+    hi = None
+    # the timed loops run on a HIGH-priority stream: the main chain is the critical path, the weight-gradient and pipeline
+    # streams (normal priority) fill what it leaves (46.7 -> 46.3 ms per step; SEG3D_BENCH_MAIN_PRIORITY=0 = default stream).
+    # It is entered BEFORE the DDP wrapper is built: DDP stashes the parameters' AccumulateGrad nodes with the stream
+    # current at construction, and a backward pass on another stream then synchronises at every one of them (one-rank
+    # rehearsal: 79.7 instead of 46.9 ms per step -- what the first multi-GPU run would have hit)
+    if dev.type == "cuda" and os.environ.get("SEG3D_BENCH_MAIN_PRIORITY", "-1") == "-1":
+        hi = torch.cuda.Stream(device=dev, priority=-1)
+        hi.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hi)
     train = args.mode == "fwdbwd"
     net = model
     if train and distributed:  # tools/train.py:246-247, 276-279
@@ -479,13 +489,6 @@ def main():
         pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
         return D.aggregate_throughput(sec, pts, dev)
 
-    hi = None
-    # the timed loops run on a HIGH-priority stream: the main chain is the critical path, the weight-gradient and pipeline
-    # streams (normal priority) fill what it leaves (46.7 -> 46.3 ms per step; SEG3D_BENCH_MAIN_PRIORITY=0 = default stream)
-    if dev.type == "cuda" and os.environ.get("SEG3D_BENCH_MAIN_PRIORITY", "-1") == "-1":
-        hi = torch.cuda.Stream(device=dev, priority=-1)
-        hi.wait_stream(torch.cuda.current_stream(dev))
-        torch.cuda.set_stream(hi)
     weights_l1 = None
     nosync_ms = None
     if train:

@@ -413,6 +413,23 @@ int seg3d_knn_attention_bwd(const float* q, const float* k, const float* v, cons
                             const int32_t* pair_offsets, int64_t n, int64_t n_src, int32_t n_neighbors, int32_t d,
                             float scale, float* dq, float* dk, float* dv, float* scratch, void* stream);
 
+/* SURVEY 8(f) rank 3  OCR's SpatialGatherModule -- seg3d/models/layers/ocr.py:10-36: per sample b (a span of rows:
+ * offsets [batch] = cumulative row counts, the stride-8 level is sorted by batch index) and class k,
+ *     context[b, k, :] = sum_{r in b} softmax_r(scale * probs[r, k]) * feats[r, :]
+ * instead of a Python loop over the samples with boolean masks.  feats [m, c], probs [m, classes <= 32];
+ * chunks [n_chunks][2] = (sample, first row) of every 128-row chunk in sample order, chunk_offsets [batch] = cumulative
+ * chunk counts.  weights [m, classes] (kept for the backward), partials [n_chunks, classes, c] and stats
+ * [batch, classes, 2] are caller-provided scratch; sums run in a fixed order (no atomics).  Backward returns d feats
+ * [m, c] and d probs [m, classes]; scratch = m * classes + n_chunks * classes floats. */
+int seg3d_class_context_fwd(const float* feats, const float* probs, const int32_t* offsets, const int32_t* chunks,
+                            const int32_t* chunk_offsets, int32_t n_chunks, int32_t batch, int64_t m,
+                            int32_t classes, int32_t c, float scale, float* weights, float* partials, float* stats,
+                            float* context, void* stream);
+int seg3d_class_context_bwd(const float* feats, const float* weights, const float* dcontext,
+                            const int32_t* offsets, const int32_t* chunks, const int32_t* chunk_offsets,
+                            int32_t n_chunks, int32_t batch, int64_t m, int32_t classes, int32_t c, float scale,
+                            float* dfeats, float* dprobs, float* scratch, void* stream);
+
 /* a24  VoxelToPoint.__call__ -- seg3d/ops/voxel_to_point/voxel_to_point.py:4-17
  * out[i] = feats[ids[i]] (zeros where ids[i] == -1).  Its backward is
  * seg3d_segment_reduce_fwd(dout, SUM) over the CSR of ids. */

@@ -93,6 +93,8 @@ SIGNATURES = {
     "seg3d_knn_grid_query": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_knn_query": (ctypes.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _p, _p]),
     "seg3d_gather_rows": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    "seg3d_class_context_fwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i64, _i32, _i32, _f, _p, _p, _p, _p, _p]),
+    "seg3d_class_context_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _i32, _i32, _f, _p, _p, _p, _p]),
     "seg3d_knn_attention_fwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _f, _p, _p, _p]),
     "seg3d_knn_attention_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _f, _p, _p, _p, _p, _p]),
 }

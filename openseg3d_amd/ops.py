@@ -1666,6 +1666,76 @@ def knn_attention(q, k, v, idx, invalid=None, keep=None, scale=None):
     return _KnnAttentionFn.apply(q, k, v, idx, inv, kp, (q.shape[1] ** -0.5) if scale is None else float(scale))
 
 
+class _ClassContextFn(torch.autograd.Function):
+    """OCR's SpatialGatherModule over row spans (ocr.py:10-36) -- seg3d_class_context_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, feats, probs, plan, scale):
+        feats, probs = _f32c(feats), _f32c(probs)
+        offsets, chunks, chunk_offsets, batch = plan
+        m, c = feats.shape
+        k = probs.shape[1]
+        dev = feats.device
+        n_chunks = chunks.shape[0]
+        weights = torch.empty((m, k), dtype=torch.float32, device=dev)
+        partials = torch.empty((max(n_chunks, 1), k, c), dtype=torch.float32, device=dev)
+        stats = torch.empty((batch, k, 2), dtype=torch.float32, device=dev)
+        context = torch.empty((batch, k, c), dtype=torch.float32, device=dev)
+        _lib.call("seg3d_class_context_fwd", _ptr(feats), _ptr(probs), _ptr(offsets), _ptr(chunks), _ptr(chunk_offsets),
+                  n_chunks, batch, m, k, c, float(scale), _ptr(weights), _ptr(partials), _ptr(stats), _ptr(context), _stream())
+        ctx.save_for_backward(feats, weights)
+        ctx.plan, ctx.scale = plan, scale
+        return context
+
+    @staticmethod
+    def backward(ctx, dcontext):
+        feats, weights = ctx.saved_tensors
+        offsets, chunks, chunk_offsets, batch = ctx.plan
+        m, c = feats.shape
+        k = weights.shape[1]
+        dcontext = _f32c(dcontext)
+        dfeats = torch.empty_like(feats)
+        dprobs = torch.empty_like(weights)
+        scratch = torch.empty((m * k + max(chunks.shape[0], 1) * k,), dtype=torch.float32, device=feats.device)
+        _lib.call("seg3d_class_context_bwd", _ptr(feats), _ptr(weights), _ptr(dcontext), _ptr(offsets), _ptr(chunks),
+                  _ptr(chunk_offsets), chunks.shape[0], batch, m, k, c, float(ctx.scale), _ptr(dfeats), _ptr(dprobs),
+                  _ptr(scratch), _stream())
+        return dfeats, dprobs, None, None
+
+
+_CONTEXT_PLANS = {}
+
+
+def class_context_plan(row_offsets, device):
+    """Device tables of seg3d_class_context_* for cumulative per-sample row counts (python ints): offsets [B],
+    chunks [n, 2] = (sample, first row) of every 128-row chunk, chunk_offsets [B]; cached per offsets tuple."""
+    key = (tuple(int(o) for o in row_offsets), str(device))
+    plan = _CONTEXT_PLANS.get(key)
+    if plan is None:
+        chunks, chunk_offsets, lo = [], [], 0
+        for b, hi in enumerate(key[0]):
+            chunks += [(b, r) for r in range(lo, hi, 128)]
+            chunk_offsets.append(len(chunks))
+            lo = hi
+        i32 = dict(dtype=torch.int32, device=device)
+        plan = (torch.tensor(key[0], **i32), torch.tensor(chunks, **i32).reshape(-1, 2), torch.tensor(chunk_offsets, **i32),
+                len(key[0]))
+        if len(_CONTEXT_PLANS) > 16:
+            _CONTEXT_PLANS.clear()
+        _CONTEXT_PLANS[key] = plan
+    return plan
+
+
+def class_context(feats, probs, row_offsets, scale=1.0):
+    """context [B, classes, C] = per sample (rows offsets[b-1] .. offsets[b]) softmax over the sample's rows of
+    scale * probs[:, k], times feats (SpatialGatherModule, seg3d/models/layers/ocr.py:10-36), any batch size in one
+    launch sequence, differentiable w.r.t. feats and probs.  row_offsets: cumulative row counts per sample (python ints)."""
+    _need_gpu(feats, probs)
+    if probs.shape[1] > 32 or feats.shape[1] % 4 or feats.shape[1] > 1024:
+        raise _lib.Seg3dError("class_context: at most 32 classes, channels a multiple of 4 and <= 1024")
+    return _ClassContextFn.apply(feats, probs, class_context_plan(row_offsets, feats.device), float(scale))
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f): labels
 def prepare_voxel_labels(point_voxel_ids, point_labels, n_voxels, ignore_index=255, cur_point_indices=None):
     """``WaymoDataset.prepare_voxel_labels`` (waymo_dataset.py:213-246) on the device: uint8 [n_voxels], the most

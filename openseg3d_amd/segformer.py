@@ -147,8 +147,12 @@ class UpBlock(spconv.SparseModule):
         t = self.transform(x_lateral)
         cat = torch.cat([x_bottom.features, t.features], dim=1)
         m = self.bottleneck(t.replace_feature(cat)).features
-        # channel_reduction (pointtransformer.py:88-102): sum adjacent channel pairs of the concat
-        skip = cat.view(cat.shape[0], m.shape[1], -1).sum(dim=2)
+        # channel_reduction (pointtransformer.py:88-102): sum adjacent channel pairs of the concat -- as an elementwise add of
+        # the two strided halves (torch's generic reduce kernel over a size-2 dimension took 66 us per call, forward and backward)
+        if cat.shape[1] == 2 * m.shape[1]:
+            skip = cat[:, 0::2] + cat[:, 1::2]
+        else:
+            skip = cat.view(cat.shape[0], m.shape[1], -1).sum(dim=2)
         return self.out(t.replace_feature(m + skip))
 
 

@@ -59,6 +59,9 @@ class SpatialGatherModule(nn.Module):
         self.scale = scale
 
     def forward(self, feats, probs, batch_size, batch_indices, offsets=None):
+        if offsets is not None and feats.is_cuda and probs.shape[1] <= 32 and feats.shape[1] % 4 == 0 and feats.shape[1] <= 1024:
+            # samples are row spans: one segmented softmax-matmul for the whole batch (seg3d_class_context_fwd / _bwd)
+            return ops.class_context(feats, probs, offsets[:batch_size], self.scale)
         out = []
         for i in range(batch_size):
             sel = slice(offsets[i - 1] if i else 0, offsets[i]) if offsets is not None else batch_indices == i

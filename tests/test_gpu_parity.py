@@ -769,10 +769,13 @@ def test_bf16_storage_conv_matches_fp32_storage_conv(dev, golden_dir, monkeypatc
     res = torch.randn(m, cout, generator=gen).to(dev)
     packed = ops.pack_weight(w, ops.PACK_FWD, use_registry=False)
     with torch.no_grad():
-        for xin in (x, x.bfloat16()):
+        # (float32 rows into the float32-in kernel; float32 rows rounded once by the wrapper -- its default; bf16 rows)
+        for xin, round_inputs in ((x, False), (x, True), (x.bfloat16(), True)):
+            monkeypatch.setattr(ops, "STORAGE_ROUND_INPUTS", round_inputs)
             for addend, relu in ((None, False), (res, True)):
                 monkeypatch.setattr(ops, "STORAGE", "fp32")
-                ref = ops.conv_act(xin.float(), nbr, packed, bias, cin, cout, None,
+                x_ref = xin.bfloat16().float() if round_inputs else xin.float()
+                ref = ops.conv_act(x_ref, nbr, packed, bias, cin, cout, None,
                                    None if addend is None else addend.bfloat16().float(), relu)
                 monkeypatch.setattr(ops, "STORAGE", "bf16")
                 got = ops.conv_act(xin, nbr, packed, bias, cin, cout, None, addend, relu)
@@ -781,3 +784,38 @@ def test_bf16_storage_conv_matches_fp32_storage_conv(dev, golden_dir, monkeypatc
                 # minus the a_lo . w_hi terms that are exactly zero for bf16 rows)
                 ulp = ref.abs().clamp(min=1e-30) * 2.0 ** -8
                 assert bool(((got.float() - ref).abs() <= ulp + 1e-6).all()), (str(xin.dtype), relu)
+
+
+@pytest.mark.parametrize("rows", [[700], [300, 0, 517], [129, 128, 1, 2000]])
+def test_class_context_matches_the_reference_loop(dev, rows):
+    """OCR's SpatialGatherModule (seg3d/models/layers/ocr.py:10-36: per sample, softmax of the class scores over the
+    sample's voxels, times the features) as one segmented launch sequence for any batch size (seg3d_class_context_fwd /
+    _bwd) against the reference's per-sample loop in fp64 autograd: context, d feats, d probs; an empty sample gives a zero
+    context; the fixed-order sums make forward and backward bit-reproducible."""
+    from openseg3d_amd import ops
+    gen = torch.Generator().manual_seed(sum(rows))
+    m, k, c, scale = sum(rows), 22, 128, 1.0
+    feats = torch.randn(m, c, generator=gen)
+    probs = torch.randn(m, k, generator=gen) * 3.0
+    g = torch.randn(len(rows), k, c, generator=gen)
+    offsets = np.cumsum(rows).tolist()
+    fr, pr = feats.double().requires_grad_(), probs.double().requires_grad_()
+    out, lo = [], 0
+    for hi in offsets:  # ocr.py:22-33
+        prob = torch.softmax(scale * pr[lo:hi].t(), dim=1) if hi > lo else pr.new_zeros((k, 0))
+        out.append(prob @ fr[lo:hi])
+        lo = hi
+    ref = torch.stack(out)
+    ref.backward(g.double())
+    fg, pg = feats.to(dev).requires_grad_(), probs.to(dev).requires_grad_()
+    ctx = ops.class_context(fg, pg, offsets, scale)
+    ctx.backward(g.to(dev))
+    assert ctx.shape == ref.shape
+    assert float((ctx.detach().cpu().double() - ref.detach()).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((fg.grad.cpu().double() - fr.grad).abs().max()) < 2e-5 * max(1.0, float(fr.grad.abs().max()))
+    assert float((pg.grad.cpu().double() - pr.grad).abs().max()) < 1e-4 * max(1.0, float(pr.grad.abs().max()))
+    first = (ctx.detach().clone(), fg.grad.clone(), pg.grad.clone())
+    fg.grad = pg.grad = None
+    again = ops.class_context(fg, pg, offsets, scale)
+    again.backward(g.to(dev))
+    assert torch.equal(first[0], again) and torch.equal(first[1], fg.grad) and torch.equal(first[2], pg.grad)
