@@ -19,13 +19,13 @@ int attn_fused_fwd_launch(const float* q, const float* k, const float* v, int ld
                           const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles,
                           const int32_t* chunk_item, int n_chunks, int heads, int dh, const float* tau, float tau_min,
                           float* out, float* lse, float dropout_p, uint64_t seed, hipStream_t st);
-size_t attn_fused_bwd_workspace_bytes(int n_tiles, int n_chunks, int heads, int dh);  // attention_fused_bwd.hip
+size_t attn_fused_bwd_workspace_bytes(int64_t m, int n_tiles, int n_chunks, int heads, int dh);  // attention_fused_bwd.hip
 bool attn_fused_bwd_supported(int heads, int dh);
 int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                           const int32_t* win_count, const int32_t* tile_item, int n_tiles, const int32_t* chunk_item,
-                          int n_chunks, int heads, int dh, const float* tau, float tau_min, float* dq, float* dk, float* dv,
-                          int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
+                          int n_chunks, int64_t m, int heads, int dh, const float* tau, float tau_min, float* dq, float* dk,
+                          float* dv, int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
                           hipStream_t st);
 bool attn_small_supported(int heads, int dh);  // attention_small.hip
 int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
@@ -58,12 +58,12 @@ int seg3d_window_attn_supported(int32_t heads, int32_t dh) {
 }
 
 // Bytes for the kernels seg3d_window_attn_fwd / _bwd take with these arguments: nothing in the forward, one tau-gradient
-// partial per wave (fused) or per tile (vector-ALU) in the backward.
+// partial per wave (fused) or per tile (vector-ALU) in the backward, plus <dO, O> per (token, head) between its two passes.
 size_t seg3d_window_attn_workspace_bytes(int64_t m, int32_t n_tiles, int32_t heads, int32_t dh) {
     if (m < 0 || heads <= 0 || n_tiles < 0) return 0;
     size_t bwd = 0;
     switch (bwd_path(heads, dh)) {
-        case 0: bwd = attn_fused_bwd_workspace_bytes(n_tiles, n_tiles, heads, dh); break;  // chunks <= tiles
+        case 0: bwd = attn_fused_bwd_workspace_bytes(m, n_tiles, n_tiles, heads, dh); break;  // chunks <= tiles
         case 1: bwd = (size_t)n_tiles * sizeof(float); break;
         default: return 0;
     }
@@ -112,9 +112,9 @@ int seg3d_window_attn_bwd(const float* q, const float* k, const float* v, int32_
     const int path = bwd_path(heads, dh);
     if (path < 0) return SEG3D_EINVAL;
     if (path == 0) {
-        if (workspace_bytes < attn_fused_bwd_workspace_bytes(n_tiles, n_qgroups, heads, dh)) return SEG3D_EWORKSPACE;
+        if (workspace_bytes < attn_fused_bwd_workspace_bytes(m, n_tiles, n_qgroups, heads, dh)) return SEG3D_EWORKSPACE;
         return attn_fused_bwd_launch(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, tile_item, n_tiles,
-                                     qg_item, n_qgroups, heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau,
+                                     qg_item, n_qgroups, m, heads, dh, tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau,
                                      workspace, drop, as_stream(stream));
     }
     if (workspace_bytes < (size_t)n_tiles * sizeof(float)) return SEG3D_EWORKSPACE;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
     const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
     int lddq, float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, float* __restrict__ tau_part,
-    DropoutParams drop) {
+    float* __restrict__ delta_buf, DropoutParams drop) {
     using C = Cfg<DH>;
     constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW;
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const int st_ld = MODE == 0 ? (st_which == 0 ? ldk : ldv) : (st_which == 0 ? ldq : c_all);
     const int st_col = C::kNarrow ? (h0 + C::HPT * st_part) * DH : h0 * DH + st_part * CT;
     const float st_scale = MODE == 0 ? 1.0f : qscale;
-    float st_reg[CT], st_out[MODE == 1 ? CT : 1];
-    float st_lse = 0.f;
+    float st_reg[CT];
+    float st_lse = 0.f, st_delta = 0.f;
     auto load_tok = [&](int t) {
         int kk = t * 32 + st_key;
         kk = kk < n ? kk : n - 1;  // clamped rows are finite and masked by p = 0
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     auto stage_load = [&](int32_t token_row) {
         load_row(st_src + (int64_t)token_row * st_ld + st_col, st_reg);
         if constexpr (MODE == 1) {
-            if (st_which == 1) {  // delta = <dO, O> and the LSE of the streamed query ride along with its dO row
-                load_row(out + (int64_t)token_row * c_all + st_col, st_out);
+            if (st_which == 1) {  // delta = <dO, O> (written per (token, head) by pass Q) and the LSE of the streamed query
+                st_delta = delta_buf[(int64_t)token_row * heads + (C::kNarrow ? h0 + st_part : h0)];
                 st_lse = lse[(int64_t)token_row * heads + (C::kNarrow ? h0 + st_part : h0)];
             }
         }
@@ -216,10 +216,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 }
             }
             if constexpr (MODE == 1) {
-                float dsum = 0.f;
-#pragma unroll
-                for (int d = 0; d < CT; ++d) dsum = fmaf(st_reg[d], st_out[d], dsum);
-                if (!C::kNarrow) dsum = quad_sum(dsum);
+                const float dsum = st_delta;
                 const int hh = C::kNarrow ? st_part : 0;
                 if (C::kNarrow || st_part == 0) {
                     float* ld = ld_lds + buf * 2 * HG * 32;
@@ -305,6 +302,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 dsum += __shfl_xor(dsum, 32, SEG3D_WAVE);
                 dl[j] = dsum;
                 lq[j] = have ? lse[(int64_t)token[j] * heads + h] * kLog2e : 0.f;
+                if (have && g == 0) delta_buf[(int64_t)token[j] * heads + h] = dsum;  // pass KV reads it instead of the O rows
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -549,18 +547,19 @@ template <int DH>
 int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out, const float* dout,
            const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count, const int2* tile_item,
            int n_tiles, const int2* chunk_item, int n_chunks, int heads, const float* tau, float tau_min, float* dq, float* dk,
-           float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part, const DropoutParams& drop, hipStream_t st) {
+           float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part, float* delta_buf, const DropoutParams& drop,
+           hipStream_t st) {
     using C = Cfg<DH>;
     const int2* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
     const dim3 grid((unsigned)(bwd_blocks(n_items, heads / C::HG)));
     hipLaunchKernelGGL((attn_fused_bwd<DH, 0>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
-                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, drop);
+                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, delta_buf, drop);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(tau_reduce_fused, dim3(1), dim3(1024), 0, st, tau_part, (int)(grid.x * 4), dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_fused_bwd<DH, 1>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
-                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, drop);
+                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, delta_buf, drop);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -575,25 +574,31 @@ bool attn_fused_bwd_supported(int heads, int dh) {
     return (dh == 12 && heads % 4 == 0) || dh == 24 || dh == 48;
 }
 
-// floats of workspace the fused backward needs (one dtau partial per wave of pass Q)
-size_t attn_fused_bwd_workspace_bytes(int n_tiles, int n_chunks, int heads, int dh) {
+static size_t tau_part_bytes(int n_tiles, int n_chunks, int heads, int dh) {
     const size_t blocks = (dh <= 12) ? bwd_blocks(n_tiles, heads / 4) : bwd_blocks(n_chunks, heads);
-    return blocks * 4 * sizeof(float) + 256;
+    return align_up(blocks * 4 * sizeof(float), 256);
+}
+
+// one dtau partial per wave of pass Q + delta = <dO, O> per (token, head), handed from pass Q to pass KV
+size_t attn_fused_bwd_workspace_bytes(int64_t m, int n_tiles, int n_chunks, int heads, int dh) {
+    return tau_part_bytes(n_tiles, n_chunks, heads, dh) + align_up((size_t)m * heads * sizeof(float), 256) + 256;
 }
 
 int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                           const int32_t* win_count, const int32_t* tile_item, int n_tiles, const int32_t* chunk_item,
-                          int n_chunks, int heads, int dh, const float* tau, float tau_min, float* dq, float* dk, float* dv,
-                          int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
+                          int n_chunks, int64_t m, int heads, int dh, const float* tau, float tau_min, float* dq, float* dk,
+                          float* dv, int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
                           hipStream_t st) {
+    (void)m;
     const int2* ti = reinterpret_cast<const int2*>(tile_item);
     const int2* ci = reinterpret_cast<const int2*>(chunk_item);
     float* tau_part = static_cast<float*>(workspace);
+    float* delta_buf = reinterpret_cast<float*>(static_cast<char*>(workspace) + tau_part_bytes(n_tiles, n_chunks, heads, dh));
 #define SEG3D_FB(D)                                                                                                        \
     case D:                                                                                                                \
         return launch<D>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, ci, n_chunks, heads, \
-                         tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st)
+                         tau, tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, delta_buf, drop, st)
     switch (dh) {
         SEG3D_FB(6);
         SEG3D_FB(12);
