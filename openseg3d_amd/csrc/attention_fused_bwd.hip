@@ -80,7 +80,19 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
     constexpr int NBQ = (DH + 15) / 16;  // 16-row d-blocks of a gradient
     static_assert(C::UW == 1, "one (tile, head) unit per wave");
-    __shared__ __attribute__((aligned(16))) char lds[C::NBUF * C::kTile + (MODE == 1 ? C::NBUF * (2 * HG * 32 + HG * 16) * 4 : 0)];
+    // stationary side (this workgroup's own tokens): two images [row][head][DHS] (hi | lo planes each) that all 256 threads
+    // fill with whole 16-B pieces of the rows -- as the forward stages its queries -- plus token / LSE / delta per row
+    constexpr int SROWS = QT * 32;
+    constexpr int SRS = HG * DHS * 2 + (DH == 48 ? 0 : 16);  // bytes per row per plane
+    constexpr int kSPlane = SROWS * SRS;
+    constexpr int kStreamBytes = C::NBUF * C::kTile + (MODE == 1 ? C::NBUF * (2 * HG * 32 + HG * 16) * 4 : 0);
+    constexpr int kStatBytes = 4 * kSPlane + SROWS * 4 + 2 * SROWS * HG * 4;
+    __shared__ __attribute__((aligned(16))) char lds[kStreamBytes + kStatBytes];
+    char* const sa_lds = lds + kStreamBytes;            // image A: Q~ (MODE 0) / K^ (MODE 1)
+    char* const sb_lds = sa_lds + 2 * kSPlane;          // image B: dO (MODE 0) / V (MODE 1)
+    int32_t* const stok_lds = reinterpret_cast<int32_t*>(sb_lds + 2 * kSPlane);
+    float* const slse_lds = reinterpret_cast<float*>(stok_lds + SROWS);  // MODE 0: [row][head] log2-domain LSE, then delta
+    float* const sdel_lds = slse_lds + SROWS * HG;
     float* ld_lds = reinterpret_cast<float*>(lds + C::NBUF * C::kTile);  // MODE 1: [buf][L | delta][head][32 tokens]
     // MODE 1: dropout hash state of the streamed query pairs, [buf][head][16 pairs] (attn_dropout.hpp: the two-round part of
     // the hash, once per query pair and tile instead of once per 2 x 2 block and lane)
@@ -253,65 +265,103 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                                    : dropout_key_term(s0 + 16 * j + c16);
     }
     float lq[2] = {0.f, 0.f}, dl[2] = {0.f, 0.f};                // MODE 0: log2-domain LSE and delta of the lane's queries
-    int32_t token[2];
+    int32_t token[2] = {-1, -1};
+    // Stationary rows -> LDS.  Narrow heads: 32 rows x 4 heads, threads 0 .. 127 (one head of one row each); wide heads: up to
+    // 128 rows of one head, two passes of 64 rows x 4 threads (a quarter of the head each).  The earlier prologue had every
+    // lane fetch its fragment-shaped 8-B pieces straight from global memory (12-24 scattered loads per lane and tensor, the
+    // normalisation repeated by the four lanes of a row): 25-40 % of a workgroup's life (tools/probes/attn_stamps.py).
     {
+        constexpr int SP = C::kNarrow ? 1 : 2;
+        const bool s_role = C::kNarrow ? tid < 128 : true;
+        const int s_row0 = C::kNarrow ? (tid & 127) >> 2 : tid >> 2;
+        const int n_srows = min(SROWS, n - item.y * SROWS);
         const float* a_src = MODE == 0 ? q : k;
         const int a_ld = MODE == 0 ? ldq : ldk;
         const float* b_src = MODE == 0 ? dout : v;
         const int b_ld = MODE == 0 ? c_all : ldv;
+        float ra[SP][CT], rb[SP][CT], ro[MODE == 0 ? SP : 1][CT];
+        int32_t stok[SP];
+        float slse[SP];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int si = s0 + 16 * j + c16;
-            token[j] = -1;
-            if (!active || (j == 1 && !two)) {  // no such token group: skip the normalise / split prologue (wave-uniform)
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    a_hi[j][s] = a_lo[j][s] = b_hi[j][s] = b_lo[j][s] = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
-                continue;
-            }
-            const bool have = si < n;
-            token[j] = have ? tok[start + si] : -1;
-            const float* arow = a_src + (int64_t)(have ? token[j] : 0) * a_ld + h * DH;
-            const float* brow = b_src + (int64_t)(have ? token[j] : 0) * b_ld + h * DH;
-            const float* orow = out + (int64_t)(have ? token[j] : 0) * c_all + h * DH;
-            float xa[KS][8], xb[KS][8];
-            float ss = 0.f, dsum = 0.f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c0 = 32 * s + 8 * g + 2 * i;
-                    f32x2 av = {0.f, 0.f}, bv = {0.f, 0.f};
-                    if (have && c0 < DH) {
-                        av = *reinterpret_cast<const f32x2*>(arow + c0);
-                        bv = *reinterpret_cast<const f32x2*>(brow + c0);
-                        if constexpr (MODE == 0) {
-                            const f32x2 ov = *reinterpret_cast<const f32x2*>(orow + c0);
-                            dsum = fmaf(bv[0], ov[0], fmaf(bv[1], ov[1], dsum));
-                        }
-                    }
-                    xa[s][2 * i] = av[0]; xa[s][2 * i + 1] = av[1];
-                    xb[s][2 * i] = bv[0]; xb[s][2 * i + 1] = bv[1];
-                    ss = fmaf(av[0], av[0], fmaf(av[1], av[1], ss));
-                }
-            ss += __shfl_xor(ss, 16, SEG3D_WAVE);
-            ss += __shfl_xor(ss, 32, SEG3D_WAVE);
-            const float r = (MODE == 0 ? qscale : 1.0f) * inv_norm(ss);
-            if constexpr (MODE == 0) {
-                dsum += __shfl_xor(dsum, 16, SEG3D_WAVE);
-                dsum += __shfl_xor(dsum, 32, SEG3D_WAVE);
-                dl[j] = dsum;
-                lq[j] = have ? lse[(int64_t)token[j] * heads + h] * kLog2e : 0.f;
-                if (have && g == 0) delta_buf[(int64_t)token[j] * heads + h] = dsum;  // pass KV reads it instead of the O rows
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xa[s][i] *= r;
-                split_frag(xa[s], &a_hi[j][s], &a_lo[j][s]);
-                split_frag(xb[s], &b_hi[j][s], &b_lo[j][s]);
+        for (int p = 0; p < SP; ++p) {
+            stok[p] = 0;
+            slse[p] = 0.f;
+            if (s_role && (p == 0 || n_srows > 64)) {
+                const int si = item.y * SROWS + s_row0 + 64 * p;
+                stok[p] = tok[start + (si < n ? si : n - 1)];
             }
         }
+#pragma unroll
+        for (int p = 0; p < SP; ++p)
+            if (s_role && (p == 0 || n_srows > 64)) {
+                load_row(a_src + (int64_t)stok[p] * a_ld + st_col, ra[p]);
+                load_row(b_src + (int64_t)stok[p] * b_ld + st_col, rb[p]);
+                if constexpr (MODE == 0) {
+                    load_row(out + (int64_t)stok[p] * c_all + st_col, ro[p]);
+                    slse[p] = lse[(int64_t)stok[p] * heads + (C::kNarrow ? h0 + st_part : h0)];
+                }
+            }
+#pragma unroll
+        for (int p = 0; p < SP; ++p)
+            if (s_role && (p == 0 || n_srows > 64)) {
+                const int row = s_row0 + 64 * p;
+                const bool have = item.y * SROWS + row < n;
+                // image A: normalised (x qscale for queries), split
+                char* da = sa_lds + row * SRS;
+                char* db = sb_lds + row * SRS;
+                if constexpr (C::kNarrow) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int d = 0; d < DH; ++d) ss = fmaf(ra[p][d], ra[p][d], ss);
+                    const float r = (MODE == 0 ? qscale : 1.0f) * inv_norm(ss);
+                    uint32_t hi[DHS / 2], lo[DHS / 2], bhi[DHS / 2], blo[DHS / 2];
+#pragma unroll
+                    for (int i = 0; i < DHS / 2; ++i) {
+                        const float a0 = 2 * i < DH ? ra[p][2 * i] * r : 0.f, a1 = 2 * i + 1 < DH ? ra[p][2 * i + 1] * r : 0.f;
+                        const float b0 = 2 * i < DH ? rb[p][2 * i] : 0.f, b1 = 2 * i + 1 < DH ? rb[p][2 * i + 1] : 0.f;
+                        split2(a0, a1, &hi[i], &lo[i]);
+                        split2(b0, b1, &bhi[i], &blo[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < DHS / 8; ++i) {
+                        char* pa = da + (st_part * DHS) * 2 + 16 * i;
+                        char* pb = db + (st_part * DHS) * 2 + 16 * i;
+                        *reinterpret_cast<u32x4*>(pa) = (u32x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
+                        *reinterpret_cast<u32x4*>(pa + kSPlane) = (u32x4){lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+                        *reinterpret_cast<u32x4*>(pb) = (u32x4){bhi[4 * i], bhi[4 * i + 1], bhi[4 * i + 2], bhi[4 * i + 3]};
+                        *reinterpret_cast<u32x4*>(pb + kSPlane) = (u32x4){blo[4 * i], blo[4 * i + 1], blo[4 * i + 2], blo[4 * i + 3]};
+                    }
+                } else {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int d = 0; d < CT; ++d) ss = fmaf(ra[p][d], ra[p][d], ss);
+                    ss = quad_sum(ss);
+                    const float r = (MODE == 0 ? qscale : 1.0f) * inv_norm(ss);
+#pragma unroll
+                    for (int i = 0; i < CT / 2; ++i) {
+                        uint32_t hi, lo, bhi, blo;
+                        split2(ra[p][2 * i] * r, ra[p][2 * i + 1] * r, &hi, &lo);
+                        split2(rb[p][2 * i], rb[p][2 * i + 1], &bhi, &blo);
+                        *reinterpret_cast<uint32_t*>(da + (st_part * CT) * 2 + 4 * i) = hi;
+                        *reinterpret_cast<uint32_t*>(da + kSPlane + (st_part * CT) * 2 + 4 * i) = lo;
+                        *reinterpret_cast<uint32_t*>(db + (st_part * CT) * 2 + 4 * i) = bhi;
+                        *reinterpret_cast<uint32_t*>(db + kSPlane + (st_part * CT) * 2 + 4 * i) = blo;
+                    }
+                }
+                if (C::kNarrow ? st_part == 0 : st_part == 0) stok_lds[row] = have ? stok[p] : -1;
+                if constexpr (MODE == 0) {
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int d = 0; d < CT; ++d) dsum = fmaf(rb[p][d], ro[p][d], dsum);
+                    if (!C::kNarrow) dsum = quad_sum(dsum);
+                    const int hs = C::kNarrow ? st_part : 0;
+                    if (C::kNarrow || st_part == 0) {
+                        slse_lds[row * HG + hs] = slse[p] * kLog2e;
+                        sdel_lds[row * HG + hs] = dsum;
+                        if (have) delta_buf[(int64_t)stok[p] * heads + h0 + hs] = dsum;  // pass KV reads it instead of the O rows
+                    }
+                }
+            }
     }
 
     // ---------------------------------------------------------------- fragment reads of a staged tile
@@ -450,6 +500,36 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     {
         stage_store(0, 0);
         __syncthreads();
+        // this wave's stationary fragments (row fragments of both images), token, LSE and delta of its rows
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool have_j = active && (j == 0 || two);
+            const int row = st_tile * 32 + 16 * j + c16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c0 = 32 * ks + 8 * g;
+                u32x4 ah = {0u, 0u, 0u, 0u}, al = ah, bh = ah, bl = ah;
+                if (have_j && c0 < DHS) {
+                    const char* pa = sa_lds + row * SRS + (hh * DHS + c0) * 2;
+                    const char* pb = sb_lds + row * SRS + (hh * DHS + c0) * 2;
+                    ah = *reinterpret_cast<const u32x4*>(pa);
+                    al = *reinterpret_cast<const u32x4*>(pa + kSPlane);
+                    bh = *reinterpret_cast<const u32x4*>(pb);
+                    bl = *reinterpret_cast<const u32x4*>(pb + kSPlane);
+                }
+                a_hi[j][ks] = __builtin_bit_cast(bf16x8, ah);
+                a_lo[j][ks] = __builtin_bit_cast(bf16x8, al);
+                b_hi[j][ks] = __builtin_bit_cast(bf16x8, bh);
+                b_lo[j][ks] = __builtin_bit_cast(bf16x8, bl);
+            }
+            if (have_j) {
+                token[j] = stok_lds[row];
+                if constexpr (MODE == 0) {
+                    lq[j] = slse_lds[row * HG + hh];
+                    dl[j] = sdel_lds[row * HG + hh];
+                }
+            }
+        }
         for (int t = 0; t < n_t; ++t) {
             const bool more = t + 1 < n_t;
             const int buf = C::NBUF == 2 ? (t & 1) : 0;
