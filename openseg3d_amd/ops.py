@@ -212,6 +212,7 @@ def probe_deferred_join(device):
     pr["done"] = True
     if _process_group_exists():  # never deferred in such a process anyway
         return None
+    before = WGRAD_DEFER
     try:
         with torch.cuda.device(device), torch.enable_grad():
             gen = torch.Generator().manual_seed(11)
@@ -230,16 +231,21 @@ def probe_deferred_join(device):
                     if defer:
                         side = side_stream(device)
                         side.wait_stream(torch.cuda.current_stream(device))
-                        with torch.cuda.stream(side):  # ~1 ms of work in front of the weight gradients
-                            big = torch.empty((2048, 2048), device=device).normal_()
-                            for _ in range(8):
-                                big = big @ big * 1e-3
+                        with torch.cuda.stream(side):  # ~30 ms of work in front of the weight gradients -- far longer than
+                            # the host needs to enqueue the pass and the copies below (no use of the global generators:
+                            # the probe must not shift the run's DropPath / dropout draws)
+                            if hasattr(torch.cuda, "_sleep"):
+                                torch.cuda._sleep(3_000_000)  # spins on s_memtime: 100 MHz on gfx950
+                            else:
+                                big = torch.full((4096, 4096), 1e-4, device=device)
+                                for _ in range(24):
+                                    big = big @ big
                         junk = [torch.full((c, c), float("nan"), device=device) for _ in range(4)]
                         del junk  # the blocks the gradient buffers are most likely to be carved from
                     y = linear(torch.relu(linear(x, ws[0], bs[0])), ws[1], bs[1])
                     y.backward(g)
                 finally:
-                    WGRAD_DEFER = True
+                    WGRAD_DEFER = before
                 # what the optimizer would read: copies enqueued on the CURRENT stream right behind the pass, no device
                 # synchronisation in between -- a missing join shows as the poison (or as stale bytes) in these copies
                 return [None if t.grad is None else t.grad.clone() for t in ws + bs]
@@ -1032,6 +1038,54 @@ def _sync_batch_norm_act(x, bn, relu, res, group):
         inv_count = (1.0 / total).to(torch.float32).contiguous()
     return _SyncBatchNormActFn.apply(xc, res, bn.weight, bn.bias, mean.contiguous(), rstd.contiguous(), scale, shift, inv_count,
                                      bool(relu), group)
+
+
+class _SpanMeanFn(torch.autograd.Function):
+    """Column means of contiguous row spans: out[b] = mean(x[offsets[b-1] : offsets[b]], dim=0)."""
+
+    @staticmethod
+    def forward(ctx, x, offsets):
+        x = _f32c(x)
+        c = x.shape[1]
+        out = torch.zeros((len(offsets), c), dtype=torch.float32, device=x.device)
+        lo = 0
+        for b, hi in enumerate(offsets):
+            rows = hi - lo
+            if rows > 0:
+                sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+                ws_bytes = _lib.query("seg3d_batchnorm_workspace_bytes", rows, c)
+                ws = _workspace(ws_bytes, x.device)
+                _lib.call("seg3d_colstats", ctypes.c_void_p(x.data_ptr() + 4 * lo * c), rows, c, _ptr(sums), _ptr(ws), ws_bytes,
+                          _stream())
+                out[b] = x[lo] + sums[0] / rows  # shifted sums: mean = x[first row] + mean of (x - x[first row])
+            lo = hi
+        ctx.offsets, ctx.rows = tuple(offsets), x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pieces, lo = [], 0
+        for b, hi in enumerate(ctx.offsets):
+            if hi > lo:
+                pieces.append((g[b] / (hi - lo)).expand(hi - lo, g.shape[1]))
+            lo = hi
+        if lo < ctx.rows:
+            pieces.append(g.new_zeros((ctx.rows - lo, g.shape[1])))
+        return (torch.cat(pieces) if len(pieces) != 1 else pieces[0].contiguous()), None
+
+
+def span_mean(x, row_offsets):
+    """[B, C] column means of the contiguous row spans given by cumulative python-int offsets (FlattenSELayer's scatter-mean
+    over the batch index, se_layer.py:24-25, on collated rows).  Per-block partial sums in a fixed order (seg3d_colstats):
+    deterministic, and -- unlike torch's two-stage reduce over ~1e5 rows, which did not replay correctly from a captured
+    hipGraph once its input had new values (tools/probes/graph_dbg.py) -- a plain launch sequence."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024):
+        lo, out = 0, []
+        for hi in row_offsets:
+            out.append(x[lo:hi].mean(dim=0) if hi > lo else x.new_zeros(x.shape[1]))
+            lo = hi
+        return torch.stack(out)
+    return _SpanMeanFn.apply(x, [int(o) for o in row_offsets])
 
 
 def narrow_batch_norm(x, bn):

@@ -107,7 +107,7 @@ class FlattenSELayer(nn.Module):
         if row_offsets is not None:
             starts = [0] + list(row_offsets[:-1])
             spans = [(s, e) for s, e in zip(starts, row_offsets)]
-            pooled = torch.stack([x[s:e].mean(dim=0) if e > s else x.new_zeros(x.shape[1]) for s, e in spans])
+            pooled = ops.span_mean(x, row_offsets)
             gate = self.fc(pooled)
             # broadcast per contiguous sample: the backward is a row sum, not an index_put over N rows
             return torch.cat([x[s:e] * gate[b] for b, (s, e) in enumerate(spans)], dim=0)

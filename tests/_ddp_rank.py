@@ -43,7 +43,8 @@ def main():
     out = {"rank": rank, "world": world, "backend": dist.get_backend(), "total": float(sum(fp.values())),
            "n_nonfinite": int(sum(1 for v in fp.values() if v != v)), "probe": probe.double().flatten()[:64].tolist(),
            "deferred_in_this_process": bool(ops._DEFERRED["seen"]) or bool(ops._DEFERRED["fix"])}
-    print("DDPRANK " + json.dumps(out), flush=True)
+    sys.stdout.write("\nDDPRANK " + json.dumps(out) + "\n")  # one write: the ranks share the pipe
+    sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()
 

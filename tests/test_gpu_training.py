@@ -476,7 +476,8 @@ def _ddp_ranks(world, backend, env=None):
     out = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env=dict(os.environ, SEG3D_DDP_BACKEND=backend, **(env or {})))
     assert out.returncode == 0, out.stderr[-3000:]
-    recs = [json.loads(l[len("DDPRANK "):]) for l in out.stdout.splitlines() if l.startswith("DDPRANK ")]
+    dec = json.JSONDecoder()  # the ranks write to one pipe: two records may share a line
+    recs = [dec.raw_decode(part.lstrip())[0] for part in out.stdout.split("DDPRANK ")[1:]]
     assert len(recs) == world
     return sorted(recs, key=lambda r: r["rank"])
 
