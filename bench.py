@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
 MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md:43
-PMC_TRAFFIC_FILES = ("r02_pmc_conv_traffic.json",)
+PMC_TRAFFIC_FILES = ("r03_pmc_conv_traffic.json", "r03_pmc_conv_traffic_dense2m.json", "r03_pmc_conv_traffic_cylinder.json",
+                     "r03_pmc_conv_traffic_multi_sweeps.json", "r03_pmc_conv_traffic_spnet.json", "r02_pmc_conv_traffic.json")
 ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
 
 WORKLOADS = {

@@ -487,7 +487,12 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
                         for (int b = 0; b < NB; ++b) {
                             f32x4 acc = o_acc[jj][b];
                             if constexpr (!FIXED) acc = acc * alpha;
+#ifdef SEG3D_ATTN_PV2  // (experiment, not shipped: P . V with two products -- p's low half dropped)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_lo[b], p_hi, acc, 0, 0, 0);
+                            o_acc[jj][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi[b], p_hi, acc, 0, 0, 0);
+#else
                             o_acc[jj][b] = mfma3(v_hi[b], v_lo[b], p_hi, p_lo, acc);
+#endif
                         }
                     }
                 }

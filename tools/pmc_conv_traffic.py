@@ -1,4 +1,4 @@
-"""Build profiles/r02_pmc_conv_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+"""Build profiles/rNN_pmc_conv_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
 `bench.py --mode fwd --steps 2 --warmup 1 --no-cpu-baseline` and the per-layer list bench.py writes.
 
 usage: python tools/pmc_conv_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <bench_layers.json> <out.json>
@@ -6,6 +6,7 @@ Correction (MI355X_MICROARCH.md, HBM section): counter unit KiB; FETCH_SIZE coun
 gfx950 -> doubled; WRITE_SIZE taken as is.
 """
 import csv
+import re
 import json
 import sys
 
@@ -14,7 +15,8 @@ def conv_dispatches(path, counter):
     per = {}
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if "spconv_split_kernel" not in n or "false>" not in n or r["Counter_Name"] != counter:
+        # sparse instantiations: spconv_split_kernel<NBT, RB, DENSE = false, IO>
+        if not re.search(r"spconv_split_kernel<\d+, \d+, false", n) or r["Counter_Name"] != counter:
             continue
         d = int(r["Dispatch_Id"])
         per[d] = (n, per.get(d, (n, 0.0))[1] + float(r["Counter_Value"]))

@@ -39,7 +39,8 @@ def main():
         for r in csv.DictReader(f):
             rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     rows.sort(key=lambda r: r[1])
-    opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r[0] or "fused_sgd" in r[0].lower()]
+    # the optimizer's own launches only: `_foreach_add_` on the BatchNorm step counters is a multi_tensor_apply kernel too
+    opt = [i for i, r in enumerate(rows) if "FusedSgd" in r[0] or "fused_sgd" in r[0].lower()]
     groups = []
     for i in opt:
         if groups and rows[i][1] - rows[groups[-1][-1]][2] < 1_000_000:
