@@ -211,6 +211,19 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
 size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int32_t cout);
 int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,
                        float* db /* [cout] or NULL */, void* workspace, size_t workspace_bytes, void* stream);
+/* The two halves of seg3d_linear_wgrad apart (same kernels): seg3d_linear_wgrad_partials leaves the per-chunk partial
+ * blocks part[chunks][cin*cout + cout] in the workspace and reports the chunk count through *chunks (host memory; 0 when
+ * m == 0); seg3d_reduce_partials sums part[chunks][n] in a fixed order into dw[0, nw) and db[0, n - nw) (db nullable; n, nw
+ * multiples of 4; chunks == 0 writes zeros).  seg3d_reduce_partials_batched runs many such sums in ONE launch: jobs =
+ * device array of { const float* part; float* dw; float* db; int64_t n, nw; int32_t chunks, reserved; int64_t first_block }
+ * (56 bytes) sorted by first_block, a job owning ceil(n / 256) blocks; total_blocks = their sum.  A training step's
+ * ~160 parameter-gradient sums (Linear weights / biases, LayerNorm gamma / beta) become one launch at the end of the
+ * backward pass (openseg3d_amd/ops.py, deferred join).  The reference has no counterpart: torch.autograd sums inside each
+ * layer's own GEMM / reduction kernels (point_transformer_layer.py:260-298). */
+int seg3d_linear_wgrad_partials(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, int32_t with_bias,
+                                void* workspace, size_t workspace_bytes, int32_t* chunks, void* stream);
+int seg3d_reduce_partials(const float* part, int32_t chunks, int64_t n, int64_t nw, float* dw, float* db, void* stream);
+int seg3d_reduce_partials_batched(const void* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
 /* a6  exact-fp32 variant for the per-point MLPs (segformer.py:21-32,58-76), whose split-bf16 forward error would land
  * directly on the logits: the same contract as seg3d_linear_* on v_mfma_f32_16x16x4_f32;
  * cin, cout multiples of 16.  Forward: transpose = 0; input gradient: transpose = 1 with cin/cout swapped. */
@@ -357,6 +370,11 @@ size_t seg3d_layernorm_bwd_workspace_bytes(int64_t m, int32_t c);
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* rowscale, int64_t m, int32_t c, float* dx,
                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* seg3d_layernorm_bwd without its final sum: dx now, the per-block partial sums of dgamma / dbeta left in the workspace as
+ * part[*nblocks][2][c] -- a seg3d_reduce_partials job with n = 2 c, nw = c, dw = dgamma, db = dbeta. */
+int seg3d_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, const float* rowscale, int64_t m, int32_t c, float* dx,
+                                 void* workspace, size_t workspace_bytes, int32_t* nblocks, void* stream);
 size_t seg3d_batchnorm_workspace_bytes(int64_t m, int32_t c);
 int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* workspace, size_t workspace_bytes,
                    void* stream);

@@ -414,6 +414,33 @@ size_t seg3d_layernorm_bwd_workspace_bytes(int64_t m, int32_t c) {
     return (size_t)kLnBwdMaxBlocks * 2 * c * sizeof(float);
 }
 
+// dx now, the per-block partial sums of dgamma / dbeta left in the workspace as part[nblocks][2][c]: their fixed-order
+// sum is a seg3d_reduce_partials job (n = 2 c, nw = c, dw = dgamma, db = dbeta) the caller runs alone or batched.
+int seg3d_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* rowscale, int64_t m, int32_t c, float* dx, void* workspace,
+                                 size_t workspace_bytes, int32_t* nblocks, void* stream) {
+    if (m < 0 || bad_c(c) || c > 512 || !nblocks) return SEG3D_EINVAL;
+    if (workspace_bytes < seg3d_layernorm_bwd_workspace_bytes(m, c) || !workspace) return SEG3D_EWORKSPACE;
+    *nblocks = 0;
+    if (m == 0) return SEG3D_OK;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx) return SEG3D_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    const RowMap rm = row_map(c);
+    unsigned nb = blocks_for(m, 4 * (64 / rm.p) * 4);
+    if (nb > (unsigned)kLnBwdMaxBlocks) nb = kLnBwdMaxBlocks;
+    const size_t smem = (size_t)4 * (64 / rm.p) * 2 * c * sizeof(float);
+    if (rm.items == 1)
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c, rm,
+                           dx, part);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(kThreads), smem, st, dy, x, mean, rstd, gamma, rowscale, m, c, rm,
+                           dx, part);
+    SEG3D_CHECK_LAUNCH();
+    *nblocks = (int32_t)nb;
+    return SEG3D_OK;
+}
+
 int seg3d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* rowscale, int64_t m, int32_t c, float* dx, float* dgamma, float* dbeta,
                         void* workspace, size_t workspace_bytes, void* stream) {

@@ -192,12 +192,11 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
 // dw[i] / db[i - nw] = sum over chunks of part[c][i] in a fixed order: a workgroup owns 64 column quads (16-B loads, 1 KiB
 // per wave instruction), its 4 chunk lanes take chunks q, q+4, .. with four independent accumulators (loads in flight
 // instead of a serial chain) and are combined through LDS in lane order.  n and nw are multiples of 4.
-__global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restrict__ part, int chunks, int64_t n,
-                                                          int64_t nw, float* __restrict__ dw,
-                                                          float* __restrict__ db) {
+__device__ __forceinline__ void reduce_block(const float* __restrict__ part, int chunks, int64_t n, int64_t nw,
+                                             float* __restrict__ dw, float* __restrict__ db, int64_t block) {
     __shared__ float4 red[4][64];
     const int cq = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t i = ((int64_t)blockIdx.x * 64 + cq) * 4;
+    const int64_t i = (block * 64 + cq) * 4;
     float4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -234,6 +233,35 @@ __global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_dense_reduce(const float* __restrict__ part, int chunks, int64_t n,
+                                                          int64_t nw, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+    reduce_block(part, chunks, n, nw, dw, db, (int64_t)blockIdx.x);
+}
+
+// Many such reduces in ONE launch (all parameter-gradient partials of a backward pass whose join was deferred to the
+// pass's end: ~160 launches of 5-7 us each otherwise).  jobs are sorted by first_block; a block finds its job by bisection.
+struct ReduceJob {
+    const float* part;
+    float* dw;
+    float* db;
+    int64_t n, nw;
+    int32_t chunks, reserved;
+    int64_t first_block;
+};
+static_assert(sizeof(ReduceJob) == 56, "ReduceJob layout is part of the C ABI (seg3d_reduce_partials_batched)");
+
+__global__ __launch_bounds__(256) void reduce_partials_batched(const ReduceJob* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {  // last job with first_block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int64_t)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const ReduceJob jb = jobs[lo];
+    reduce_block(jb.part, jb.chunks, jb.n, jb.nw, jb.dw, jb.db, (int64_t)blockIdx.x - jb.first_block);
+}
+
 }  // namespace
 
 // part[chunks][n] -> dw[0, nw) and db[0, n - nw) (db nullable); also used by the sparse wgrad (wgrad_split.hip)
@@ -247,6 +275,41 @@ extern "C" size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int
     if (m < 0 || cin <= 0 || cout <= 0) return 0;
     const Plan p = plan(m, cin, cout);
     return ((size_t)p.chunks * ((size_t)cin * cout + cout) + 64) * sizeof(float);
+}
+
+// The two halves of seg3d_linear_wgrad apart: partial blocks now, their fixed-order sum later (alone, or batched with the
+// other pending sums of a backward pass).  *chunks receives the number of partial blocks written (0 when m == 0).
+extern "C" int seg3d_linear_wgrad_partials(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout,
+                                           int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks,
+                                           void* stream) {
+    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || !chunks) return SEG3D_EINVAL;
+    if (m > 0 && (!x || !dy)) return SEG3D_EINVAL;
+    if (workspace_bytes < seg3d_linear_wgrad_workspace_bytes(m, cin, cout) || (m > 0 && !workspace)) return SEG3D_EINVAL;
+    *chunks = 0;
+    if (m == 0) return SEG3D_OK;
+    const Plan p = plan(m, cin, cout);
+    const int tiles = p.nbo * p.nbi;
+    const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
+    hipLaunchKernelGGL(wgrad_dense_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), x, dy, m, cin, cout,
+                       (int)p.rows, p.nbi, tiles, static_cast<float*>(workspace), with_bias ? 1 : 0);
+    SEG3D_CHECK_LAUNCH();
+    *chunks = p.chunks;
+    return SEG3D_OK;
+}
+
+extern "C" int seg3d_reduce_partials(const float* part, int32_t chunks, int64_t n, int64_t nw, float* dw, float* db,
+                                     void* stream) {
+    if (chunks < 0 || n <= 0 || nw < 0 || nw > n || (n & 3) || (nw & 3) || !dw || (chunks > 0 && !part)) return SEG3D_EINVAL;
+    return wgrad_chunk_reduce(part, chunks, n, nw, dw, db, as_stream(stream));
+}
+
+extern "C" int seg3d_reduce_partials_batched(const void* jobs, int32_t n_jobs, int64_t total_blocks, void* stream) {
+    if (n_jobs < 0 || total_blocks < 0 || total_blocks > 0x7FFFFFFF || (n_jobs > 0 && !jobs)) return SEG3D_EINVAL;
+    if (n_jobs == 0 || total_blocks == 0) return SEG3D_OK;
+    hipLaunchKernelGGL(reduce_partials_batched, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                       static_cast<const ReduceJob*>(jobs), (int)n_jobs);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
 }
 
 extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, float* dw,

@@ -69,7 +69,9 @@ class _WgradFork:
     def __init__(self, device):
         self.on = WGRAD_STREAM and device.type == "cuda"
         self.keep = []
+        self.jobs = []  # pending fixed-order sums of this function's partial blocks (see add_reduce)
         self.used = False
+        self.device = device
         if self.on:
             self.main = torch.cuda.current_stream(device)
             self.side = side_stream(device)
@@ -88,6 +90,12 @@ class _WgradFork:
     def hold(self, *tensors):
         self.keep.extend(tensors)
 
+    def add_reduce(self, part, chunks, n, nw, dw_ptr, db_ptr, *keep):
+        """Queue the fixed-order sum of part[chunks][n] into dw[0, nw) / db[0, n - nw) (raw device addresses; db_ptr 0 =
+        none).  It runs at join(): on its own when the function joins at once, in ONE launch with every other pending
+        sum of the backward pass when the join is deferred to the pass's end (~160 launches of 5-7 us otherwise)."""
+        self.jobs.append((part, int(chunks), int(n), int(nw), int(dw_ptr), int(db_ptr or 0), keep))
+
     def join(self, *grads):
         """grads: (parameter, gradient launched on the side stream) pairs -- decides whether the wait may be deferred to
         the end of the backward pass (below); gradients that are None are ignored."""
@@ -95,10 +103,20 @@ class _WgradFork:
             _drop_stale_deferred()
             if WGRAD_DEFER and _defer_join(self, [(w, gr) for w, gr in grads if gr is not None and w is not None]):
                 return
+            # joining now: this function's sums, and every sum still pending from functions that deferred earlier in the
+            # pass -- what joins here may be ADDED to one of their gradients by the engine (a parameter used twice)
+            jobs = _DEFERRED["jobs"] + self.jobs
+            _DEFERRED["jobs"] = []
+            if jobs:  # (partial blocks written on the current stream, e.g. LayerNorm's, must be visible to the side stream)
+                self.side.wait_stream(self.main)
+                _run_reduce_jobs(jobs, self.device, self.side)
             ev = torch.cuda.Event()
             ev.record(self.side)
             self.main.wait_event(ev)
+        elif self.jobs:
+            _run_reduce_jobs(self.jobs, self.device, None)
         self.keep = []
+        self.jobs = []
 
 
 # Deferred join (the default in single-process training): instead of waiting at the end of every backward function, the
@@ -123,7 +141,7 @@ class _WgradFork:
 # exception (the engine then skips its final callbacks) leaves state that the first deferral of the NEXT pass drops after
 # joining the streams.  SEG3D_WGRAD_DEFER=0 turns deferral off.
 WGRAD_DEFER = os.environ.get("SEG3D_WGRAD_DEFER", "1") != "0"
-_DEFERRED = {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": [], "task": None}
+_DEFERRED = {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": [], "task": None, "jobs": []}
 _DEFER_PROBE = {"done": False, "ok": None}
 
 
@@ -135,6 +153,40 @@ def _graph_task_id():
 def _reset_deferred():
     st = _DEFERRED
     st["keep"], st["main"], st["side"], st["seen"], st["twice"], st["fix"], st["task"] = [], None, None, set(), set(), [], None
+    st["jobs"] = []
+
+
+_REDUCE_JOB = None
+
+
+def _run_reduce_jobs(jobs, device, stream):
+    """The queued partial-block sums (see _WgradFork.add_reduce) on `stream` (a torch stream; None = the current one): one
+    launch each for up to two, otherwise ONE launch over a device job table (seg3d_reduce_partials_batched)."""
+    global _REDUCE_JOB
+    if not jobs:
+        return
+    sp = _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+    if len(jobs) <= 2:
+        for part, chunks, n, nw, dw, db, _ in jobs:
+            _lib.call("seg3d_reduce_partials", _ptr(part), chunks, n, nw, ctypes.c_void_p(dw), ctypes.c_void_p(db) if db else None, sp)
+        return
+    import contextlib
+    import numpy as np
+    if _REDUCE_JOB is None:
+        _REDUCE_JOB = np.dtype([("part", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("n", "<i8"), ("nw", "<i8"), ("chunks", "<i4"),
+                                ("reserved", "<i4"), ("first_block", "<i8")])
+        assert _REDUCE_JOB.itemsize == 56
+    rec = np.zeros((len(jobs),), dtype=_REDUCE_JOB)
+    first = 0
+    for i, (part, chunks, n, nw, dw, db, _) in enumerate(jobs):
+        rec[i] = (part.data_ptr() if chunks else 0, dw, db, n, nw, chunks, 0, first)
+        first += (n + 255) // 256
+    # pinned staging block from torch's caching host allocator: it is not handed out again before the copy below has run
+    host = torch.empty((rec.nbytes,), dtype=torch.uint8, pin_memory=True)
+    host.numpy()[:] = rec.view(np.uint8)
+    with (contextlib.nullcontext() if stream is None else torch.cuda.stream(stream)):
+        table = host.to(device, non_blocking=True)
+        _lib.call("seg3d_reduce_partials_batched", _ptr(table), len(jobs), first, sp)
 
 
 def _process_group_exists():
@@ -146,6 +198,9 @@ def _final_join():
     st = _DEFERRED
     if st["side"] is None:
         return
+    if st["jobs"]:  # every pending partial-block sum of the pass in one launch, behind the last producer on either stream
+        st["side"].wait_stream(st["main"])
+        _run_reduce_jobs(st["jobs"], st["jobs_device"], st["side"])
     st["main"].wait_stream(st["side"])
     # AccumulateGrad stores the incoming tensor itself when nobody else references it (the normal case: the gradient
     # buffers below are aliases with their own TensorImpl, made for this check) and CLONES it otherwise -- a clone taken
@@ -194,7 +249,10 @@ def _defer_join(fk, grads):
             st["keep"].append(gr.detach())  # gradient of a view of the parameter: autograd scatters it, no .grad to check
     st["main"], st["side"], st["task"] = fk.main, fk.side, task
     st["keep"].append(fk.keep)
+    st["jobs"].extend(fk.jobs)
+    st["jobs_device"] = fk.device
     fk.keep = []
+    fk.jobs = []
     return True
 
 
@@ -776,10 +834,7 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             if want_db:  # column sums of dy ride along with the weight-gradient pass
                 db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
-            ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
-            _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws),
-                      ws_bytes, fk.fork(ws, dy, x))
+            _linear_wgrad_into(fk, x, dy, cin, cout, dw.data_ptr(), db.data_ptr() if want_db else 0)
         elif want_db:
             db = dy.sum(0)
         if ctx.needs_input_grad[0]:
@@ -822,10 +877,7 @@ class _LinearOddShapeFn(torch.autograd.Function):
             dyp = torch.nn.functional.pad(dy, (0, po)) if po else dy
             dwp = torch.empty((cout + po, cin + pi), dtype=torch.float32, device=dy.device)
             dbp = torch.empty((cout + po,), dtype=torch.float32, device=dy.device) if want_db else None
-            ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin + pi, cout + po)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
-            _lib.call("seg3d_linear_wgrad", _ptr(xp), _ptr(dyp), x.shape[0], cin + pi, cout + po, _ptr(dwp), _ptr(dbp),
-                      _ptr(ws), ws_bytes, fk.fork(ws, xp, dyp))
+            _linear_wgrad_into(fk, xp, dyp, cin + pi, cout + po, dwp.data_ptr(), dbp.data_ptr() if want_db else 0)
             dw = dwp[:cout, :cin]
             if want_db:
                 db = dbp[:cout]
@@ -890,6 +942,13 @@ class _LayerNormResidualFn(torch.autograd.Function):
         db = torch.empty((c,), dtype=torch.float32, device=x.device)
         ws_bytes = _lib.query("seg3d_layernorm_bwd_workspace_bytes", m, c)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+        fork = getattr(ctx, "fork", None)
+        if fork is not None:  # an enclosing layer function joins for us: dgamma / dbeta's fixed-order sum is queued on its fork
+            nb = ctypes.c_int32(0)
+            _lib.call("seg3d_layernorm_bwd_partials", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rs), m, c,
+                      _ptr(dx), _ptr(ws), ws_bytes, ctypes.byref(nb), _stream())
+            fork.add_reduce(ws, nb.value, 2 * c, c, dg.data_ptr(), db.data_ptr())
+            return dx, (dy if ctx.has_res else None), dg, db, None, None
         _lib.call("seg3d_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rs), m, c, _ptr(dx),
                   _ptr(dg), _ptr(db), _ptr(ws), ws_bytes, _stream())
         return dx, (dy if ctx.has_res else None), dg, db, None, None
@@ -1380,10 +1439,7 @@ class _AttnInProjFn(torch.autograd.Function):
             dw = torch.empty((3 * c, c), dtype=torch.float32, device=x.device)
             db = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
             for src, dy, r0, rows in ((xp, dqk, 0, 2 * c), (x, dv, 2 * c, c)):
-                ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, c, rows)
-                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-                _lib.call("seg3d_linear_wgrad", _ptr(src), _ptr(dy), m, c, rows, ctypes.c_void_p(dw.data_ptr() + 4 * r0 * c),
-                          ctypes.c_void_p(db.data_ptr() + 4 * r0), _ptr(ws), ws_bytes, fk.fork(ws, dy, src))
+                _linear_wgrad_into(fk, src, dy, c, rows, dw.data_ptr() + 4 * r0 * c, db.data_ptr() + 4 * r0)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             # an enclosing layer function may hand over the residual path's gradient: it rides in the same epilogue
             extra = None if ctx.needs_input_grad[1] else getattr(ctx, "dx_addend", None)
@@ -1422,11 +1478,28 @@ def _linear_wgrad(x, dy, cin, cout, want_db=True, fork=None):
     fork: a _WgradFork of the calling backward function -- the launch goes to the side stream, the caller joins."""
     dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
     db = torch.empty((cout,), dtype=torch.float32, device=dy.device) if want_db else None
+    if fork is not None:
+        _linear_wgrad_into(fork, x, dy, cin, cout, dw.data_ptr(), db.data_ptr() if want_db else 0)
+        return dw, db
     ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", x.shape[0], cin, cout)
     ws = _workspace(ws_bytes, dy.device)
-    st = fork.fork(ws, x, dy) if fork is not None else _stream()
-    _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, st)
+    _lib.call("seg3d_linear_wgrad", _ptr(x), _ptr(dy), x.shape[0], cin, cout, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream())
     return dw, db
+
+
+def _linear_wgrad_into(fk, x, dy, cin, cout, dw_ptr, db_ptr, *keep):
+    """Dense weight gradient in two halves: the partial blocks per row chunk now, on fk's stream; their fixed-order sum
+    queued on fk (it runs at fk.join(): alone, or batched with every other pending sum at the end of the backward pass
+    when the join is deferred).  dw_ptr / db_ptr: device addresses of [cout, cin] / [cout] (0 = no bias gradient); the
+    caller keeps those tensors alive until its join (queued jobs hold addresses only: a second reference to a gradient
+    tensor would make AccumulateGrad clone it instead of keeping it)."""
+    m = x.shape[0]
+    ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, cin, cout)
+    ws = _workspace(ws_bytes, dy.device)
+    chunks = ctypes.c_int32(0)
+    _lib.call("seg3d_linear_wgrad_partials", _ptr(x), _ptr(dy), m, cin, cout, 1 if db_ptr else 0, _ptr(ws), ws_bytes,
+              ctypes.byref(chunks), fk.fork(ws, x, dy, *keep))
+    fk.add_reduce(ws, chunks.value, cin * cout + cout, cin * cout, dw_ptr, db_ptr, *keep)
 
 
 class _Ctx:
@@ -1471,6 +1544,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.parts = (c_in, c_at, c_n1, c_n2)
         ctx.save_for_backward(o, x1, h, g, w_out, w1, w2)
         ctx.bias_params = (b_out, b1, b2)
+        ctx.norm_params = (g1, be1, g2, be2)
         return x2
 
     @staticmethod
@@ -1483,6 +1557,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         # the three weight gradients of this function go to the side stream as soon as their operands are enqueued and
         # co-run with the chain below (the attention backward is the long pole); one join at the end
         fk = _WgradFork(dx2.device)
+        c_n1.fork = c_n2.fork = fk
         dm, _, dg2, dbe2, _, _ = _LayerNormResidualFn.backward(c_n2, dx2)
         dw2, db2 = _linear_wgrad(g, dm, hid, c, fork=fk)
         dh = torch.ops.aten.gelu_backward(_linear_apply(dm, _linear_pack(w2, 1), None, c, hid), h)
@@ -1496,7 +1571,10 @@ class _EncoderLayerFn(torch.autograd.Function):
         c_in.dx_addend = d_x1
         dx, _, dw_in, db_in = _AttnInProjFn.backward(c_in, dqk, dv)
         b_out, b1, b2 = ctx.bias_params
-        fk.join((w_out, dw_out), (w1, dw1), (w2, dw2), (b_out, db_out), (b1, db1), (b2, db2))
+        g1, be1, g2, be2 = ctx.norm_params
+        fk.join((w_out, dw_out), (w1, dw1), (w2, dw2), (b_out, db_out), (b1, db1), (b2, db2), (g1, dg1), (be1, dbe1),
+                (g2, dg2), (be2, dbe2))
+        c_n1.fork = c_n2.fork = None
         ctx.parts = None
         return dx, None, dw_in, db_in, dtau, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, None
 

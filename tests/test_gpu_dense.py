@@ -117,3 +117,62 @@ def test_batched_pack_refresh_matches_single_packs():
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert a.shape == b.shape and torch.equal(a, b), rnd
+
+
+def test_batched_partial_sums_match_the_single_launch_entries():
+    """seg3d_linear_wgrad_partials + seg3d_reduce_partials_batched (all parameter-gradient sums of a backward pass in ONE
+    launch, ops._run_reduce_jobs) against the entries that sum at once: the same kernels and the same summation order, so
+    Linear dw / db come out bit-identical; LayerNorm's dgamma / dbeta (whose own reduce kernel sums in another order) are
+    compared with float64.  Includes an empty job (m = 0 -> zeros) and the 2-job path that launches singly."""
+    import ctypes
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    p, st = ops._ptr, ops._stream
+    fk = ops._WgradFork(dev)
+    fk.on = False  # everything on the current stream: this test is about the sums, not the streams
+    want, got = [], []
+    for m, cin, cout in [(20000, 48, 96), (777, 192, 192), (0, 96, 48), (5001, 64, 16)]:
+        x, dy = torch.randn(m, cin, device=dev), torch.randn(m, cout, device=dev)
+        dw, db = torch.empty(cout, cin, device=dev), torch.empty(cout, device=dev)
+        nbytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, cin, cout)
+        ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+        _lib.call("seg3d_linear_wgrad", p(x), p(dy), m, cin, cout, p(dw), p(db), p(ws), nbytes, st())
+        want.append((dw, db))
+        dw2, db2 = torch.full_like(dw, float("nan")), torch.full_like(db, float("nan"))
+        ops._linear_wgrad_into(fk, x, dy, cin, cout, dw2.data_ptr(), db2.data_ptr())
+        got.append((dw2, db2))
+    m, c = 30000, 96
+    x, dy = torch.randn(m, c, device=dev), torch.randn(m, c, device=dev)
+    gamma = torch.randn(c, device=dev)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    dx, dg, dbe = torch.empty_like(x), torch.full((c,), float("nan"), device=dev), torch.full((c,), float("nan"), device=dev)
+    nbytes = _lib.query("seg3d_layernorm_bwd_workspace_bytes", m, c)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    nb = ctypes.c_int32(0)
+    _lib.call("seg3d_layernorm_bwd_partials", p(dy), p(x), p(mean), p(rstd), p(gamma), p(None), m, c, p(dx), p(ws), nbytes,
+              ctypes.byref(nb), st())
+    assert nb.value > 0
+    fk.add_reduce(ws, nb.value, 2 * c, c, dg.data_ptr(), dbe.data_ptr())
+    assert len(fk.jobs) == 5
+    fk.join()  # 5 jobs -> one seg3d_reduce_partials_batched launch
+    assert not fk.jobs
+    torch.cuda.synchronize()
+    for (dw, db), (dw2, db2) in zip(want, got):
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert float(got[2][0].abs().max()) == 0.0 and float(got[2][1].abs().max()) == 0.0  # m = 0
+    xh = ((x - mean[:, None]) * rstd[:, None]).double()
+    assert float((dg.double() - (dy.double() * xh).sum(0)).abs().max()) < 1e-3
+    assert float((dbe.double() - dy.double().sum(0)).abs().max()) < 1e-3
+    # one and two jobs take the single-launch entry
+    dw3 = torch.full_like(want[1][0], float("nan"))
+    x, dy = torch.randn(777, 192, device=dev), torch.randn(777, 192, device=dev)
+    ref = torch.empty_like(dw3)
+    nbytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", 777, 192, 192)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    _lib.call("seg3d_linear_wgrad", p(x), p(dy), 777, 192, 192, p(ref), p(None), p(ws), nbytes, st())
+    ops._linear_wgrad_into(fk, x, dy, 192, 192, dw3.data_ptr(), 0)
+    fk.join()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, dw3)

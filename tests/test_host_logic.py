@@ -237,7 +237,7 @@ def test_deferred_join_bookkeeping_is_safe_by_construction(monkeypatch):
         @staticmethod
         def backward(ctx, dy):
             gr = torch.full_like(ctx.w, 2.0)
-            fk = SimpleNamespace(main=FakeStream(), side=FakeStream(), keep=[gr])
+            fk = SimpleNamespace(main=FakeStream(), side=FakeStream(), keep=[gr], jobs=[], device=None)
             log.append((ops._defer_join(fk, [(ctx.w, gr)]), fk))
             return dy * ctx.w.sum(), gr
 
