@@ -168,6 +168,7 @@ class SparseUnet(nn.Module):
         level.seed_chain(3)
         for k in range(4):
             level.subm()
+            level.mask_order()
             if k >= 2:
                 level.sample_offsets()  # squeeze-excite of conv3 / conv4, OCR
             if k < 3:
