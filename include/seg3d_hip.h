@@ -258,6 +258,11 @@ int seg3d_linear_pack_weight(const float* weight, int32_t cin, int32_t cout, int
 int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
                      const float* addend /* [m, cout] added in the epilogue, or NULL */, int32_t cin, int32_t cout,
                      float* y, void* stream);
+/* y = (x + x_add) W^T + b without writing x + x_add: the q | k half of the cosine attention's in-projection reads
+ * x + pos (cosine_msa.py:58-63 via point_transformer_layer.py:289-291).  Inference path; same kernel, the sum is taken on
+ * the A operand's way into the bf16 split. */
+int seg3d_linear_fwd_sum(const float* x, const float* x_add, int64_t m, const void* w_packed, const float* bias,
+                         int32_t cin, int32_t cout, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /

@@ -59,6 +59,7 @@ SIGNATURES = {
     "seg3d_linear_packed_bytes": (_sz, [_i32, _i32, _i32]),
     "seg3d_linear_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd": (ctypes.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
+    "seg3d_linear_fwd_sum": (ctypes.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
     "seg3d_window_partition_workspace_bytes": (_sz, [_i64, _i32, _p]),
     "seg3d_window_partition": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p,
                                               _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

@@ -18,7 +18,7 @@ int spconv_split_pack(const float* weight, int cin, int cout, int kk, int transp
                       hipStream_t st);
 int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                         const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
-                        hipStream_t st);
+                        hipStream_t st, const float* x_add);
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st);
 size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
@@ -349,7 +349,7 @@ int seg3d_spconv_fwd_act_bf16(const void* x, int32_t x_bf16, const int32_t* nbr,
     if (m_out == 0) return SEG3D_OK;
     if (!x || !nbr || !y_bf16) return SEG3D_EINVAL;
     return spconv_split_fwd_io(x, nbr, m_out, w_packed_v, bias, addend_bf16, row_order, cin, cout, y_bf16, relu ? 1 : 0,
-                               x_bf16 ? 2 : 1, as_stream(stream));
+                               x_bf16 ? 2 : 1, as_stream(stream), nullptr);
 }
 
 /* a6  exact-fp32 Linear (per-point MLPs): y[m, cout] = x[m, cin] . W^T + bias on v_mfma_f32_16x16x4_f32 -- the

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
     if (t < items) pack_item(jb.src, jb.cin_src, jb.cout_src, jb.kk, jb.transpose, jb.flip, t, jb.dst);
 }
 
-// IO: storage of the activations.  0 = float32 in, float32 out (the default path); 1 = float32 in, bf16 out;
+// IO: storage of the activations.  0 = float32 in, float32 out (the default path); 3 = the same with a second float32
+// summand on the A operand (Linear layers only: y = (x + x_add) W^T + b); 1 = float32 in, bf16 out;
 // 2 = bf16 in, bf16 out (the opt-in bf16-storage mode of the sparse-conv feature maps, BASELINE configs[4]): a bf16 row
 // IS its own hi part (lo = 0), so the a_lo . w_hi product disappears -- two MFMAs per product instead of three -- and a
 // gathered row is half the bytes.  Residual addend and output share the output's storage type; accumulation, bias and
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
                                                               const float* __restrict__ bias,
                                                               const void* __restrict__ addend_v,
                                                               const int32_t* __restrict__ row_order, int cin, int cout,
-                                                              void* __restrict__ y_v, int relu) {
+                                                              void* __restrict__ y_v, int relu,
+                                                              const float* __restrict__ x_add) {
     const float* __restrict__ x = static_cast<const float*>(x_v);
     const float* __restrict__ addend = static_cast<const float*>(addend_v);
     float* __restrict__ y = static_cast<float*>(y_v);
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
             }
         };
         f32x4 areg[RB][2];
+        constexpr bool XADD = DENSE && IO == 3;  // Linear with a second summand: y = (x + x_add) W^T + b
+        f32x4 areg2[XADD ? RB : 1][2];
         bool aval[RB];
         auto issue_a = [&](const int32_t* idx, int cb, bool on) {
             const bool in_range = cb * 32 + g * 8 < cin;
@@ -258,6 +262,11 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
                     const f32x4* p = reinterpret_cast<const f32x4*>(x + src_row * cin + col);
                     areg[rb][0] = p[0];
                     areg[rb][1] = p[1];
+                    if constexpr (XADD) {  // summed in land_a, when both loads have arrived
+                        const f32x4* p2 = reinterpret_cast<const f32x4*>(x_add + src_row * cin + col);
+                        areg2[rb][0] = p2[0];
+                        areg2[rb][1] = p2[1];
+                    }
                 }
             }
         };
@@ -266,8 +275,16 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (IO == 2) a_hi[rb] = __builtin_bit_cast(bf16x8, aval[rb] ? areg[rb][0] : z);
-                else split8(aval[rb] ? areg[rb][0] : z, aval[rb] ? areg[rb][1] : z, &a_hi[rb], &a_lo[rb]);
+                if constexpr (IO == 2) {
+                    a_hi[rb] = __builtin_bit_cast(bf16x8, aval[rb] ? areg[rb][0] : z);
+                } else {
+                    f32x4 r0 = areg[rb][0], r1 = areg[rb][1];
+                    if constexpr (XADD) {
+                        r0 = r0 + areg2[rb][0];
+                        r1 = r1 + areg2[rb][1];
+                    }
+                    split8(aval[rb] ? r0 : z, aval[rb] ? r1 : z, &a_hi[rb], &a_lo[rb]);
+                }
             }
         };
 
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
             const int64_t opos = row0 + rb * 16 + g * 4 + r;
             if (opos < m_out) {
                 const int64_t orow = row_order ? (int64_t)row_order[opos] : opos;
-                if constexpr (IO != 0) {  // bf16 storage of the output (and of the residual it is added to)
+                if constexpr (IO == 1 || IO == 2) {  // bf16 storage of the output (and of the residual it is added to)
                     __bf16* yb = static_cast<__bf16*>(y_v) + orow * cout + nb0 * 16 + c16;
                     const __bf16* ab = addend_v ? static_cast<const __bf16*>(addend_v) + orow * cout + nb0 * 16 + c16 : nullptr;
 #pragma unroll
@@ -397,25 +414,29 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
 
 template <int NBT, int RB>
 int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const void* addend,
-                 const int32_t* row_order, int cin, int cout, void* y, int relu, int io, hipStream_t st) {
+                 const int32_t* row_order, int cin, int cout, void* y, int relu, int io, hipStream_t st,
+                 const float* x_add = nullptr) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
     if (io == 1 || io == 2) {  // bf16-storage variants (sparse convs only)
         if (nbr == nullptr) return SEG3D_EINVAL;
         if (io == 1)
             hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 1>), grid, dim3(256), 0, st, x, nbr, m_out,
-                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu);
+                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
         else
             hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 2>), grid, dim3(256), 0, st, x, nbr, m_out,
-                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu);
+                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
         SEG3D_CHECK_LAUNCH();
         return SEG3D_OK;
     }
-    if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
+    if (nbr == nullptr && x_add)  // Linear layer with a second summand on the A operand (IO = 3)
+        hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 3>), grid, dim3(256), 0, st, x, nbr, m_out,
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, x_add);
+    else if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr);
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -452,7 +473,8 @@ extern "C" int seg3d_debug_set_conv_nbt(int32_t nbt) {
 
 int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                         const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
-                        hipStream_t st) {
+                        hipStream_t st, const float* x_add) {
+    if (x_add && (nbr || io != 0)) return SEG3D_EINVAL;  // the second summand exists for Linear layers only
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deepest level has few rows
     // (19k) and 384+ columns: 128-column workgroups put it on the chip in ONE resident round (153 row tiles x 3 = 459 of
     // 512 slots; 96 columns = 612 = a second, mostly empty round) and gather each row 3 times instead of 4
@@ -467,19 +489,19 @@ int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const 
     else if (nb % 2 == 0) pick = 2;
     if (const int w = g_forced_nbt.load(std::memory_order_relaxed); w > 0 && nb % w == 0) pick = w;
     switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
-        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st);
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
     }
 }
 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st) {
-    return spconv_split_fwd_io(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, 0, st);
+    return spconv_split_fwd_io(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, 0, st, nullptr);
 }
 
 // ------------------------------------------------------------------ dense Linear layers through the same kernel
@@ -515,6 +537,17 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
     return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, 0, as_stream(stream));
+}
+
+// y = (x + x_add) W^T + b: the cosine attention's q | k in-projection reads x + pos (cosine_msa.py:58-63,
+// point_transformer_layer.py:289-291); the sum is taken on the A operand's way into the split, so the [rows, C] tensor
+// x + pos is never written (inference; training keeps it -- it is the weight gradient's operand).
+int seg3d_linear_fwd_sum(const float* x, const float* x_add, int64_t m, const void* w_packed, const float* bias, int32_t cin,
+                         int32_t cout, float* y, void* stream) {
+    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!x || !x_add || !y) return SEG3D_EINVAL;
+    return spconv_split_fwd_io(x, nullptr, m, w_packed, bias, nullptr, nullptr, cin, cout, y, 0, 0, as_stream(stream), x_add);
 }
 
 }  // extern "C"

@@ -1410,6 +1410,9 @@ def window_attention_packed(qk, v, tau, tau_min, heads, wi, drop_p=0.0, drop_see
     return _WindowAttnPackedFn.apply(qk, v, tau, tau_min, heads, wi, float(drop_p), int(drop_seed))
 
 
+INPROJ_SUM = os.environ.get("SEG3D_INPROJ_SUM", "1") != "0"  # 0 = the inference in-projection materialises x + pos (A/B)
+
+
 class _AttnInProjFn(torch.autograd.Function):
     """In-projection of the cosine attention (cosine_msa.py:58-63): qk = (x + pos) W_qk^T + b_qk, v = x W_v^T + b_v with
     the packed parameters in_proj_weight [3C, C] / in_proj_bias [3C].  One backward produces dx (both paths summed),
@@ -1420,6 +1423,14 @@ class _AttnInProjFn(torch.autograd.Function):
     def forward(ctx, x, pos, w_in, b_in):
         x = _f32c(x)
         c = x.shape[1]
+        if (INPROJ_SUM and not any(ctx.needs_input_grad) and pos.shape == x.shape and pos.dtype == torch.float32
+                and pos.is_contiguous()):
+            # inference: x + pos is summed on the GEMM's A operand and never written (in training it is kept: the weight
+            # gradient of the q | k rows multiplies with it)
+            qk = torch.empty((x.shape[0], 2 * c), dtype=torch.float32, device=x.device)
+            _lib.call("seg3d_linear_fwd_sum", _ptr(x), _ptr(pos), x.shape[0], _ptr(_linear_pack(w_in[: 2 * c], 0)),
+                      _ptr(b_in[: 2 * c]), c, 2 * c, _ptr(qk), _stream())
+            return qk, _linear_apply(x, _linear_pack(w_in[2 * c:], 0), b_in[2 * c:], c, c)
         xp = x + pos
         qk = _linear_apply(xp, _linear_pack(w_in[: 2 * c], 0), b_in[: 2 * c], c, 2 * c)
         v = _linear_apply(x, _linear_pack(w_in[2 * c:], 0), b_in[2 * c:], c, c)
@@ -1528,7 +1539,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         heads, tau_min, wi, eps1, eps2, s1, s2, drop_p, drop_seed = meta
         x = _f32c(x)
         c = x.shape[1]
-        c_in = _Ctx(True, False, True, True)
+        live = any(ctx.needs_input_grad)  # False under no_grad: nothing of this forward is kept
+        c_in = _Ctx(live, False, live, live)
         qk, v = _AttnInProjFn.forward(c_in, x, pos, w_in, b_in)
         c_at = _Ctx(True, True, True, False, False, False)
         o = _WindowAttnPackedFn.forward(c_at, qk, v, tau, tau_min, heads, wi, drop_p, drop_seed)

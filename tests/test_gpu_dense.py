@@ -176,3 +176,29 @@ def test_batched_partial_sums_match_the_single_launch_entries():
     fk.join()
     torch.cuda.synchronize()
     assert torch.equal(ref, dw3)
+
+
+@pytest.mark.parametrize("m,cin,cout", [(5000, 48, 96), (12345, 96, 192), (700, 192, 384), (300, 384, 768), (33, 16, 16)])
+def test_linear_with_summed_operand_matches_the_materialised_sum(m, cin, cout):
+    """seg3d_linear_fwd_sum (y = (x + x_add) W^T + b, the sum taken on the A operand's way into the split; the inference
+    in-projection's q | k half) against seg3d_linear_fwd on the materialised x + x_add: the same float32 sum, the same split,
+    the same products -- bit-identical."""
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m)
+    x, pos = torch.randn(m, cin, device=dev), torch.randn(m, cin, device=dev)
+    w, b = torch.randn(cout, cin, device=dev) / cin ** 0.5, torch.randn(cout, device=dev)
+    packed = ops._linear_pack(w, 0)
+    want = ops._linear_apply(x + pos, packed, b, cin, cout)
+    got = torch.full_like(want, float("nan"))
+    _lib.call("seg3d_linear_fwd_sum", ops._ptr(x), ops._ptr(pos), m, ops._ptr(packed), ops._ptr(b), cin, cout, ops._ptr(got),
+              ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # and through the in-projection: no_grad takes the summed-operand path, grad mode the materialised one
+    w_in, b_in = torch.randn(3 * cin, cin, device=dev) / cin ** 0.5, torch.randn(3 * cin, device=dev)
+    if cin % 16 == 0:
+        with torch.no_grad():
+            qk0, v0 = ops.attn_in_proj(x, pos, w_in, b_in)
+        qk1, v1 = ops.attn_in_proj(x.clone().requires_grad_(), pos, w_in, b_in)
+        assert torch.equal(qk0, qk1.detach()) and torch.equal(v0, v1.detach())
