@@ -263,6 +263,10 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
  * the A operand's way into the bf16 split. */
 int seg3d_linear_fwd_sum(const float* x, const float* x_add, int64_t m, const void* w_packed, const float* bias,
                          int32_t cin, int32_t cout, float* y, void* stream);
+/* y = (x W^T) * factor, elementwise ([m, cout] factor, no bias): the input gradient of the MLP's fc2 times the GELU
+ * derivative saved by the training forward (point_transformer_layer.py:260-276; torch runs a gelu_backward pass there). */
+int seg3d_linear_fwd_mul(const float* x, int64_t m, const void* w_packed, const float* factor, int32_t cin, int32_t cout,
+                         float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13, a15, a16, a18  get_window_coors / batching_single_shift / get_flat2win_inds /
@@ -386,6 +390,9 @@ int seg3d_colstats(const float* x, int64_t m, int32_t c, float* sums, void* work
 int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const float* gamma, const float* beta,
                           float momentum, float* running_mean, float* running_var, float* stats, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* GELU, erf form (torch.nn.GELU default, point_transformer_layer.py:265): g = h Phi(h); gp (nullable) = d g / d h =
+ * Phi(h) + h phi(h), written in the same pass by the training forward.  n = number of elements, a multiple of 4. */
+int seg3d_gelu_fwd(const float* h, int64_t n, float* g, float* gp, void* stream);
 int seg3d_affine_act(const float* x, const float* res, const float* scale, const float* shift, int32_t relu,
                      int64_t m, int32_t c, float* y, void* stream);
 int seg3d_batchnorm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "seg3d_linear_pack_weight": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd": (ctypes.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd_sum": (ctypes.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "seg3d_linear_fwd_mul": (ctypes.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p]),
     "seg3d_window_partition_workspace_bytes": (_sz, [_i64, _i32, _p]),
     "seg3d_window_partition": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p,
                                               _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "seg3d_colstats": (ctypes.c_int, [_p, _i64, _i32, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_batchnorm_stats": (ctypes.c_int, [_p, _i64, _i32, _f, _p, _p, _f, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_affine_act": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
+    "seg3d_gelu_fwd": (ctypes.c_int, [_p, _i64, _p, _p, _p]),
     "seg3d_batchnorm_bwd": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_batchnorm_bwd_reduce": (ctypes.c_int, [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, ctypes.c_size_t, _p]),
     "seg3d_batchnorm_bwd_apply": (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p]),

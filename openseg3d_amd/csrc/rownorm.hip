@@ -290,6 +290,26 @@ __global__ __launch_bounds__(1024) void col_sums_finish(const float* __restrict_
     if ((threadIdx.x >> 5) == 0 && i < 2 * c) sums[i] = t;
 }
 
+// GELU (erf form, torch.nn.GELU's default: point_transformer_layer.py:265) and, for the training forward, its derivative
+// in the same pass: g = h Phi(h), gp = Phi(h) + h phi(h).  The backward then needs no pass of its own -- d h = gp * (dm W2)
+// is taken in the epilogue of that GEMM (seg3d_linear_fwd_mul).
+__global__ __launch_bounds__(kThreads) void gelu_fwd_kernel(const float* __restrict__ h, int64_t quads, float* __restrict__ g,
+                                                            float* __restrict__ gp) {
+    for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < quads; t += (int64_t)gridDim.x * kThreads) {
+        const float4 v = reinterpret_cast<const float4*>(h)[t];
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float o[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float cdf = 0.5f * (1.0f + erff(in[i] * 0.70710678118654752440f));
+            o[i] = in[i] * cdf;
+            d[i] = cdf + in[i] * (0.39894228040143267794f * __expf(-0.5f * in[i] * in[i]));
+        }
+        reinterpret_cast<float4*>(g)[t] = make_float4(o[0], o[1], o[2], o[3]);
+        if (gp) reinterpret_cast<float4*>(gp)[t] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+}
+
 // y = act(x * scale + shift (+ res))
 __global__ __launch_bounds__(kThreads) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
@@ -508,6 +528,16 @@ int seg3d_batchnorm_stats(const float* x, int64_t m, int32_t c, float eps, const
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 31) / 32)), dim3(1024), 0, st, x, part, (int)nb, m, c, eps, gamma,
                        beta, momentum, running_mean, running_var, stats);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+int seg3d_gelu_fwd(const float* h, int64_t n, float* g, float* gp, void* stream) {
+    if (n < 0 || (n & 3)) return SEG3D_EINVAL;
+    if (n == 0) return SEG3D_OK;
+    if (!h || !g) return SEG3D_EINVAL;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks_for(n / 4, kThreads * 4)), dim3(kThreads), 0, as_stream(stream), h, n / 4, g,
+                       gp);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

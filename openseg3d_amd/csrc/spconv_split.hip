@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
 }
 
 // IO: storage of the activations.  0 = float32 in, float32 out (the default path); 3 = the same with a second float32
-// summand on the A operand (Linear layers only: y = (x + x_add) W^T + b); 1 = float32 in, bf16 out;
+// summand on the A operand (Linear layers only: y = (x + x_add) W^T + b); 4 = float32, the epilogue MULTIPLIES by the
+// `addend` tensor instead of adding it (Linear layers only: d h = gelu'(h) * (d m W2)); 1 = float32 in, bf16 out;
 // 2 = bf16 in, bf16 out (the opt-in bf16-storage mode of the sparse-conv feature maps, BASELINE configs[4]): a bf16 row
 // IS its own hi part (lo = 0), so the a_lo . w_hi product disappears -- two MFMAs per product instead of three -- and a
 // gathered row is half the bytes.  Residual addend and output share the output's storage type; accumulation, bias and
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
                     const float* ar = addend + orow * cout + nb0 * 16 + c16;
 #pragma unroll
                     for (int n = 0; n < NBT; ++n) {
-                        const float v = acc[rb][n][r] + ar[n * 16];
+                        // IO = 4 (Linear only): the "addend" is an elementwise factor -- y = (x W^T) * factor
+                        const float v = IO == 4 ? acc[rb][n][r] * ar[n * 16] : acc[rb][n][r] + ar[n * 16];
                         yr[n * 16] = relu ? (v < 0.0f ? 0.0f : v) : v;
                     }
                 } else {
@@ -428,7 +430,10 @@ int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* w
         SEG3D_CHECK_LAUNCH();
         return SEG3D_OK;
     }
-    if (nbr == nullptr && x_add)  // Linear layer with a second summand on the A operand (IO = 3)
+    if (nbr == nullptr && io == 4)  // Linear layer whose output is multiplied elementwise by `addend` (IO = 4)
+        hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 4>), grid, dim3(256), 0, st, x, nbr, m_out,
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr);
+    else if (nbr == nullptr && x_add)  // Linear layer with a second summand on the A operand (IO = 3)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 3>), grid, dim3(256), 0, st, x, nbr, m_out,
                            reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, x_add);
     else if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
@@ -475,6 +480,7 @@ int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const 
                         const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
                         hipStream_t st, const float* x_add) {
     if (x_add && (nbr || io != 0)) return SEG3D_EINVAL;  // the second summand exists for Linear layers only
+    if (io == 4 && (nbr || !addend)) return SEG3D_EINVAL;  // ... and so does the elementwise factor
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deepest level has few rows
     // (19k) and 384+ columns: 128-column workgroups put it on the chip in ONE resident round (153 row tiles x 3 = 459 of
     // 512 slots; 96 columns = 612 = a second, mostly empty round) and gather each row 3 times instead of 4
@@ -537,6 +543,16 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
     return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, 0, as_stream(stream));
+}
+
+// y = (x W^T) * factor, elementwise: the input gradient of fc2 times the saved GELU derivative (point_transformer_layer.py:
+// 260-276 backward) -- the gelu_backward pass over [rows, hidden] (two reads, one write) becomes one read in this epilogue.
+int seg3d_linear_fwd_mul(const float* x, int64_t m, const void* w_packed, const float* factor, int32_t cin, int32_t cout,
+                         float* y, void* stream) {
+    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!x || !factor || !y) return SEG3D_EINVAL;
+    return spconv_split_fwd_io(x, nullptr, m, w_packed, nullptr, factor, nullptr, cin, cout, y, 0, 4, as_stream(stream), nullptr);
 }
 
 // y = (x + x_add) W^T + b: the cosine attention's q | k in-projection reads x + pos (cosine_msa.py:58-63,

@@ -1524,6 +1524,9 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
+GELU_SAVED_GRAD = os.environ.get("SEG3D_GELU_SAVED_GRAD", "1") != "0"  # 0 = torch gelu + gelu_backward passes (A/B)
+
+
 class _EncoderLayerFn(torch.autograd.Function):
     """One post-norm encoder layer (point_transformer_layer.py:289-298) as a single autograd node:
         a  = out_proj(window_attention(in_proj(x, pos)))          x1 = x  + s1 * LN1(a)
@@ -1549,7 +1552,14 @@ class _EncoderLayerFn(torch.autograd.Function):
         x1 = _LayerNormResidualFn.forward(c_n1, a, x, g1, be1, eps1, s1)
         hid = w1.shape[0]
         h = _linear_apply(x1, _linear_pack(w1, 0), b1, c, hid)
-        g = torch.nn.functional.gelu(h)
+        if live and GELU_SAVED_GRAD:
+            # training: the GELU pass also writes its derivative (in h's storage's place: h is not needed again), and the
+            # backward multiplies by it in the epilogue of fc2's input-gradient GEMM -- no gelu_backward pass
+            g, gp = torch.empty_like(h), torch.empty_like(h)
+            _lib.call("seg3d_gelu_fwd", _ptr(h), h.numel(), _ptr(g), _ptr(gp), _stream())
+            h = gp
+        else:
+            g = torch.nn.functional.gelu(h)
         m = _linear_apply(g, _linear_pack(w2, 0), b2, hid, c)
         c_n2 = _Ctx(True, True, True, True, False, False)
         x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
@@ -1572,7 +1582,12 @@ class _EncoderLayerFn(torch.autograd.Function):
         c_n1.fork = c_n2.fork = fk
         dm, _, dg2, dbe2, _, _ = _LayerNormResidualFn.backward(c_n2, dx2)
         dw2, db2 = _linear_wgrad(g, dm, hid, c, fork=fk)
-        dh = torch.ops.aten.gelu_backward(_linear_apply(dm, _linear_pack(w2, 1), None, c, hid), h)
+        if GELU_SAVED_GRAD:  # h holds gelu'(fc1 output), saved by the forward
+            dh = torch.empty((dm.shape[0], hid), dtype=torch.float32, device=dm.device)
+            _lib.call("seg3d_linear_fwd_mul", _ptr(dm), dm.shape[0], _ptr(_linear_pack(w2, 1)), _ptr(h), c, hid, _ptr(dh),
+                      _stream())
+        else:
+            dh = torch.ops.aten.gelu_backward(_linear_apply(dm, _linear_pack(w2, 1), None, c, hid), h)
         dw1, db1 = _linear_wgrad(x1, dh, c, hid, fork=fk)
         d_x1 = _linear_apply(dh, _linear_pack(w1, 1), None, hid, c, addend=dx2)
         # attention branch: LN1 -> out_proj -> attention -> in_proj, d_x1 joins in the in-projection's epilogue

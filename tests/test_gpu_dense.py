@@ -202,3 +202,35 @@ def test_linear_with_summed_operand_matches_the_materialised_sum(m, cin, cout):
             qk0, v0 = ops.attn_in_proj(x, pos, w_in, b_in)
         qk1, v1 = ops.attn_in_proj(x.clone().requires_grad_(), pos, w_in, b_in)
         assert torch.equal(qk0, qk1.detach()) and torch.equal(v0, v1.detach())
+
+
+def test_gelu_with_derivative_and_multiplying_epilogue():
+    """seg3d_gelu_fwd (g and d g / d h in one pass) against torch's erf-form GELU and its autograd derivative in float64;
+    seg3d_linear_fwd_mul (y = (x W^T) * factor) against the unfused pair, bit for bit; and the two together = what
+    torch.ops.aten.gelu_backward computes in the encoder layer's backward."""
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    m, c, hid = 7001, 96, 192
+    h = (torch.randn(m, hid, device=dev) * 3.0)
+    h[0, :8] = torch.tensor([0.0, -0.0, 1e-8, -1e-8, 12.0, -12.0, 40.0, -40.0], device=dev)
+    g, gp = torch.empty_like(h), torch.empty_like(h)
+    _lib.call("seg3d_gelu_fwd", ops._ptr(h), h.numel(), ops._ptr(g), ops._ptr(gp), ops._stream())
+    hr = h.double().cpu().requires_grad_()
+    gr = torch.nn.functional.gelu(hr)
+    gr.sum().backward()
+    assert float((g.cpu().double() - gr.detach()).abs().max()) < 2e-6 * 40
+    assert float((gp.cpu().double() - hr.grad).abs().max()) < 2e-6
+    g_only = torch.empty_like(h)
+    _lib.call("seg3d_gelu_fwd", ops._ptr(h), h.numel(), ops._ptr(g_only), ops._ptr(None), ops._stream())
+    assert torch.equal(g_only, g)
+    dm = torch.randn(m, c, device=dev)
+    w2 = torch.randn(c, hid, device=dev) / hid ** 0.5  # fc2.weight [c, hid]; its input gradient is dm @ w2
+    packed_t = ops._linear_pack(w2, 1)
+    plain = ops._linear_apply(dm, packed_t, None, c, hid)
+    fused = torch.full_like(plain, float("nan"))
+    _lib.call("seg3d_linear_fwd_mul", ops._ptr(dm), m, ops._ptr(packed_t), ops._ptr(gp), c, hid, ops._ptr(fused), ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain * gp)
+    want = torch.ops.aten.gelu_backward(plain, h)
+    assert float((fused - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
