@@ -22,6 +22,7 @@
 // neighbour in the whole tile are never visited; a wave whose own rows have none skips the MFMAs.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
 // IS its own hi part (lo = 0), so the a_lo . w_hi product disappears -- two MFMAs per product instead of three -- and a
 // gathered row is half the bytes.  Residual addend and output share the output's storage type; accumulation, bias and
 // the activation stay float32.
-template <int NBT, int RB, bool DENSE, int IO = 0>
+template <int NBT, int RB, bool DENSE, int IO = 0, int DEPTH = 1>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __restrict__ x_v, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
                                                               const float* __restrict__ bias,
@@ -229,40 +230,42 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
         // j % 4.  (An LDS-DMA copy would save the registers, but the compiler then drains vmcnt before the first
         // ds_read of the current chunk -- it cannot tell the slots apart -- and nothing overlaps.)
         constexpr int kMine = (kPieces + kW - 1) / kW;
-        u32x4 wreg[kMine];  // ext-vector type: HIP's uint4 struct is not promoted out of scratch here
-        auto stage_w = [&](int k, int cb) {
+        // DEPTH register sets: loads of up to DEPTH chunks are in flight while the current one is multiplied (set index =
+        // a compile-time constant everywhere, so the sets are plain registers)
+        u32x4 wreg[DEPTH][kMine];  // ext-vector type: HIP's uint4 struct is not promoted out of scratch here
+        auto stage_w = [&](auto S, int k, int cb) {
             const uint4* src = wp + (((int64_t)k * cb_n + cb) * nb_n + nb0) * 128;
 #pragma unroll
             for (int j = 0; j < kMine; ++j) {
                 const int piece = j * kW + wave;
-                wreg[j] = *reinterpret_cast<const u32x4*>(src + (kPieces % kW == 0 || piece < kPieces ? piece : 0) * 64 + lane);
+                wreg[S][j] = *reinterpret_cast<const u32x4*>(src + (kPieces % kW == 0 || piece < kPieces ? piece : 0) * 64 + lane);
             }
         };
-        auto commit_w = [&](int buf) {
+        auto commit_w = [&](auto S, int buf) {
 #pragma unroll
             for (int j = 0; j < kMine; ++j) {
                 const int piece = j * kW + wave;
                 if (kPieces % kW == 0 || piece < kPieces)
-                    *reinterpret_cast<u32x4*>(wlds + buf * kSlot + piece * 64 + lane) = wreg[j];
+                    *reinterpret_cast<u32x4*>(wlds + buf * kSlot + piece * 64 + lane) = wreg[S][j];
             }
         };
-        f32x4 areg[RB][2];
+        f32x4 areg[DEPTH][RB][2];
         constexpr bool XADD = DENSE && IO == 3;  // Linear with a second summand: y = (x + x_add) W^T + b
         f32x4 areg2[XADD ? RB : 1][2];
-        bool aval[RB];
-        auto issue_a = [&](const int32_t* idx, int cb, bool on) {
+        bool aval[DEPTH][RB];
+        auto issue_a = [&](auto S, const int32_t* idx, int cb, bool on) {
             const bool in_range = cb * 32 + g * 8 < cin;
             const int col = in_range ? cb * 32 + g * 8 : 0;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                aval[rb] = on && in_range && idx[rb] >= 0;
+                aval[S][rb] = on && in_range && idx[rb] >= 0;
                 const int64_t src_row = idx[rb] >= 0 ? idx[rb] : 0;
                 if constexpr (IO == 2) {  // 8 bf16 = one 16-B piece
-                    areg[rb][0] = *reinterpret_cast<const f32x4*>(static_cast<const __bf16*>(x_v) + src_row * cin + col);
+                    areg[S][rb][0] = *reinterpret_cast<const f32x4*>(static_cast<const __bf16*>(x_v) + src_row * cin + col);
                 } else {
                     const f32x4* p = reinterpret_cast<const f32x4*>(x + src_row * cin + col);
-                    areg[rb][0] = p[0];
-                    areg[rb][1] = p[1];
+                    areg[S][rb][0] = p[0];
+                    areg[S][rb][1] = p[1];
                     if constexpr (XADD) {  // summed in land_a, when both loads have arrived
                         const f32x4* p2 = reinterpret_cast<const f32x4*>(x_add + src_row * cin + col);
                         areg2[rb][0] = p2[0];
@@ -272,63 +275,54 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
             }
         };
         bf16x8 a_hi[RB], a_lo[RB];
-        auto land_a = [&]() {
+        auto land_a = [&](auto S) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if constexpr (IO == 2) {
-                    a_hi[rb] = __builtin_bit_cast(bf16x8, aval[rb] ? areg[rb][0] : z);
+                    a_hi[rb] = __builtin_bit_cast(bf16x8, aval[S][rb] ? areg[S][rb][0] : z);
                 } else {
-                    f32x4 r0 = areg[rb][0], r1 = areg[rb][1];
+                    f32x4 r0 = areg[S][rb][0], r1 = areg[S][rb][1];
                     if constexpr (XADD) {
                         r0 = r0 + areg2[rb][0];
                         r1 = r1 + areg2[rb][1];
                     }
-                    split8(aval[rb] ? r0 : z, aval[rb] ? r1 : z, &a_hi[rb], &a_lo[rb]);
+                    split8(aval[S][rb] ? r0 : z, aval[S][rb] ? r1 : z, &a_hi[rb], &a_lo[rb]);
                 }
             }
         };
 
-        uint32_t todo = todo_all;
-        int k_cur = __builtin_ctz(todo);
-        todo &= todo - 1;
-        int cb_cur = 0;
-        bool on_cur = (my_mask >> k_cur) & 1u;  // wave-uniform: does any of this wave's rows have a neighbour at k_cur?
-        {
-            int32_t idx0[RB];
-            fetch_idx(k_cur, idx0);
-            // prologue: chunk 0
-            stage_w(k_cur, 0);
-            issue_a(idx0, 0, on_cur);
-        }
-        land_a();
-        commit_w(0);
-        __syncthreads();
-
-        int buf = 0;
-        STAMP(7);
-        for (;;) {
-            int k_nxt, cb_nxt = cb_cur;
-            bool have_next = true;
-            if (todo == 0u) {  // next channel slice, offsets from the start
-                cb_nxt = cb_cur + 1;
-                todo = todo_all;
-                have_next = cb_nxt < cb_n;
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, DEPTH - 1>;
+        // the chunk sequence: 32-channel slice outermost, this tile's active offsets inside
+        struct Chunk {
+            int k, cb;
+            bool on, have;
+        };
+        uint32_t it_todo = todo_all;
+        int it_cb = 0;
+        auto next_chunk = [&]() {
+            Chunk c;
+            c.have = true;
+            if (it_todo == 0u) {  // next channel slice, offsets from the start
+                it_cb += 1;
+                it_todo = todo_all;
+                c.have = it_cb < cb_n;
             }
-            k_nxt = __builtin_ctz(todo);
-            todo &= todo - 1;
-            const bool on_nxt = (my_mask >> k_nxt) & 1u;
-            if (have_next) {
-                int32_t idx_nxt[RB];
-                fetch_idx(k_nxt, idx_nxt);
-                stage_w(k_nxt, cb_nxt);
-                issue_a(idx_nxt, cb_nxt, on_nxt);
-            }
-            // (Issuing these loads between the MFMAs below instead -- one per column block -- is slower: every 1-KiB
-            // wave load holds the wave for 55-80 cycles at the CU's address unit, lanes of a quad read four different
-            // rows; spread over the MFMAs they stall the matrix pipe instead and land later.  tools/probes/conv_stamps.py)
-            STAMP(0);
-            if (on_cur) {
+            c.k = __builtin_ctz(it_todo);
+            it_todo &= it_todo - 1;
+            c.cb = it_cb;
+            c.on = (my_mask >> c.k) & 1u;  // wave-uniform: does any of this wave's rows have a neighbour at this offset?
+            return c;
+        };
+        auto issue = [&](auto S, const Chunk& c) {
+            int32_t idx[RB];
+            fetch_idx(c.k, idx);
+            stage_w(S, c.k, c.cb);
+            issue_a(S, idx, c.cb, c.on);
+        };
+        auto multiply = [&](bool on, int buf) {
+            if (on) {
                 const uint4* slot = wlds + buf * kSlot;
 #pragma unroll
                 for (int n = 0; n < NBT; ++n) {
@@ -342,25 +336,75 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
                     }
                 }
             }
-            STAMP(1);
-            if (!have_next) break;
+        };
+
+        Chunk cur = next_chunk();
+        issue(S0{}, cur);  // prologue: chunk 0
+        land_a(S0{});
+        commit_w(S0{}, 0);
+        __syncthreads();
+        int buf = 0;
+        STAMP(7);
+        if constexpr (DEPTH == 1) {
+            for (;;) {
+                const Chunk nxt = next_chunk();
+                if (nxt.have) issue(S0{}, nxt);
+                // (Issuing these loads between the MFMAs below instead -- one per column block -- is slower: every 1-KiB
+                // wave load holds the wave for 55-80 cycles at the CU's address unit, lanes of a quad read four different
+                // rows; spread over the MFMAs they stall the matrix pipe instead and land later.  tools/probes/conv_stamps.py)
+                STAMP(0);
+                multiply(cur.on, buf);
+                STAMP(1);
+                if (!nxt.have) break;
 #ifdef SEG3D_CONV_STAMP
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP(2);
 #endif
-            land_a();
-            STAMP(3);
-            commit_w(buf ^ 1);
+                land_a(S0{});
+                STAMP(3);
+                commit_w(S0{}, buf ^ 1);
 #ifdef SEG3D_CONV_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(4);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                STAMP(4);
 #endif
-            __syncthreads();
-            STAMP(5);
-            buf ^= 1;
-            k_cur = k_nxt;
-            cb_cur = cb_nxt;
-            on_cur = on_nxt;
+                __syncthreads();
+                STAMP(5);
+                buf ^= 1;
+                cur = nxt;
+            }
+        } else {
+            // Two chunks in flight (the idea: 18 - 36 MFMAs per chunk are a fraction of a gather's round trip through L2, so
+            // one look-ahead should leave a narrow layer's wave waiting for rows; measured otherwise, see conv_depth2()).
+            // Invariant at the top: `cur` is landed (slot buf); `n1` is in flight in set 1.
+            Chunk n1 = next_chunk();
+            if (n1.have) issue(S1{}, n1);
+            for (;;) {
+                Chunk n2 = n1;
+                if (n1.have) {
+                    n2 = next_chunk();
+                    if (n2.have) issue(S0{}, n2);  // set 0 was landed: free
+                }
+                multiply(cur.on, buf);
+                if (!n1.have) break;
+                land_a(S1{});
+                commit_w(S1{}, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+                // `n1` is current now, `n2` in flight in set 0
+                Chunk n3 = n2;
+                if (n2.have) {
+                    n3 = next_chunk();
+                    if (n3.have) issue(S1{}, n3);
+                }
+                multiply(n1.on, buf);
+                if (!n2.have) break;
+                land_a(S0{});
+                commit_w(S0{}, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+                cur = n2;
+                n1 = n3;
+            }
         }
     }
 
@@ -414,6 +458,19 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
 #endif
 }
 
+// SEG3D_CONV_DEPTH=2 (A/B, off by default): column-block widths up to this one run the sparse kernel with two chunks in
+// flight.  Measured on the headline scene: every narrow layer 4 - 14 % SLOWER (48 -> 48: 77 -> 82 us, 96 -> 96: 168 -> 183 us)
+// -- the second register set costs a wave of occupancy (NBT 6: 115 -> 148 VGPRs, NBT 3: 90 -> 119) and these layers are
+// bound by the rate of gather requests, not by one wave's round trip.
+constexpr int kDeepMaxNbt = 6;
+static bool conv_depth2() {
+    static const bool on = [] {
+        const char* e = getenv("SEG3D_CONV_DEPTH");
+        return e && atoi(e) == 2;
+    }();
+    return on;
+}
+
 template <int NBT, int RB>
 int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const void* addend,
                  const int32_t* row_order, int cin, int cout, void* y, int relu, int io, hipStream_t st,
@@ -439,6 +496,9 @@ int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* w
     else if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
                            reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr);
+    else if (NBT <= kDeepMaxNbt && conv_depth2())  // narrow sparse layers: two chunks in flight
+        hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 0, (NBT <= kDeepMaxNbt ? 2 : 1)>), grid, dim3(256), 0, st, x, nbr,
+                           m_out, reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
                            reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
