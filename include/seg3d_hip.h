@@ -263,6 +263,14 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
  * the A operand's way into the bf16 split. */
 int seg3d_linear_fwd_sum(const float* x, const float* x_add, int64_t m, const void* w_packed, const float* bias,
                          int32_t cin, int32_t cout, float* y, void* stream);
+/* y = res + LayerNorm(x W^T + b) in ONE launch (inference path): the encoder layer's out-projection + norm1 + residual and
+ * fc2 + norm2 + residual (point_transformer_layer.py:289-298; the reference runs Linear, LayerNorm and the add as three
+ * kernels).  The normalised row must fit one workgroup: cout in {16, 32, 48, 64, 96, 128, 192}, SEG3D_EINVAL otherwise
+ * (the caller then runs seg3d_linear_fwd + seg3d_layernorm_fwd).  res nullable.  Statistics as seg3d_layernorm_fwd takes
+ * them: two-pass mean / biased variance in float32, rstd = rsqrt(var + eps). */
+int seg3d_linear_layernorm_fwd(const float* x, int64_t m, const void* w_packed, const float* bias, const float* res,
+                               const float* gamma, const float* beta, float eps, int32_t cin, int32_t cout, float* y,
+                               void* stream);
 /* y = (x W^T) * factor, elementwise ([m, cout] factor, no bias): the input gradient of the MLP's fc2 times the GELU
  * derivative saved by the training forward (point_transformer_layer.py:260-276; torch runs a gelu_backward pass there). */
 int seg3d_linear_fwd_mul(const float* x, int64_t m, const void* w_packed, const float* factor, int32_t cin, int32_t cout,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "seg3d_linear_fwd": (ctypes.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd_sum": (ctypes.c_int, [_p, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd_mul": (ctypes.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "seg3d_linear_layernorm_fwd": (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _p, ctypes.c_float, _i32, _i32, _p, _p]),
     "seg3d_window_partition_workspace_bytes": (_sz, [_i64, _i32, _p]),
     "seg3d_window_partition": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p,
                                               _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

@@ -142,6 +142,14 @@ __global__ __launch_bounds__(256) void pack_weights_batched(const PackJob* __res
 // IS its own hi part (lo = 0), so the a_lo . w_hi product disappears -- two MFMAs per product instead of three -- and a
 // gathered row is half the bytes.  Residual addend and output share the output's storage type; accumulation, bias and
 // the activation stay float32.
+// IO = 5 (Linear only, one column group = the whole row): LayerNorm + residual in the epilogue,
+// y = res + LN(x W^T + b) (point_transformer_layer.py:289-298: x = x + norm1(attn(..)), x = x + norm2(mlp(x)))
+struct LnEpilogue {
+    const float* gamma;
+    const float* beta;
+    float eps;
+};
+
 template <int NBT, int RB, bool DENSE, int IO = 0, int DEPTH = 1>
 __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __restrict__ x_v, const int32_t* __restrict__ nbr,
                                                               int64_t m_out, const uint4* __restrict__ wp,
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
                                                               const void* __restrict__ addend_v,
                                                               const int32_t* __restrict__ row_order, int cin, int cout,
                                                               void* __restrict__ y_v, int relu,
-                                                              const float* __restrict__ x_add) {
+                                                              const float* __restrict__ x_add, LnEpilogue ln) {
     const float* __restrict__ x = static_cast<const float*>(x_v);
     const float* __restrict__ addend = static_cast<const float*>(addend_v);
     float* __restrict__ y = static_cast<float*>(y_v);
@@ -408,6 +416,50 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
         }
     }
 
+    if constexpr (IO == 5) {
+        // The workgroup's NBT column blocks are the whole row (host-checked): a row's NBT * 16 values sit in the 16 lanes of
+        // one lane group, NBT per lane.  Two-pass mean / variance in registers as rownorm.hip's ln_fwd_kernel takes them.
+        float gm[NBT], bt[NBT];
+#pragma unroll
+        for (int n = 0; n < NBT; ++n) {
+            gm[n] = ln.gamma[n * 16 + c16];
+            bt[n] = ln.beta[n * 16 + c16];
+        }
+        const float inv_c = 1.0f / (float)cout;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int n = 0; n < NBT; ++n) sum += acc[rb][n][r];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 64);
+                const float mu = sum * inv_c;
+                float ss = 0.f;
+#pragma unroll
+                for (int n = 0; n < NBT; ++n) {
+                    const float dlt = acc[rb][n][r] - mu;
+                    ss = fmaf(dlt, dlt, ss);
+                }
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) ss += __shfl_xor(ss, d, 64);
+                const float rs = rsqrtf(ss * inv_c + ln.eps);
+                const int64_t opos = row0 + rb * 16 + g * 4 + r;
+                if (opos < m_out) {
+                    float* yr = y + opos * cout + c16;
+                    const float* rr = addend ? addend + opos * cout + c16 : nullptr;
+#pragma unroll
+                    for (int n = 0; n < NBT; ++n) {
+                        float o = (acc[rb][n][r] - mu) * rs * gm[n] + bt[n];
+                        if (rr) o += rr[n * 16];
+                        yr[n * 16] = o;
+                    }
+                }
+            }
+        return;
+    }
+
     // D layout of v_mfma_f32_16x16x*: row = (lane>>4)*4 + r, col = lane & 15
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -474,34 +526,41 @@ static bool conv_depth2() {
 template <int NBT, int RB>
 int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias, const void* addend,
                  const int32_t* row_order, int cin, int cout, void* y, int relu, int io, hipStream_t st,
-                 const float* x_add = nullptr) {
+                 const float* x_add = nullptr, LnEpilogue ln = LnEpilogue{nullptr, nullptr, 0.f}) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
+    if (io == 5) {  // Linear + LayerNorm + residual: the workgroup's columns must be the whole row
+        if (nbr != nullptr || NBT * 16 != cout || !ln.gamma || !ln.beta) return SEG3D_EINVAL;
+        hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 5>), grid, dim3(256), 0, st, x, nbr, m_out,
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, 0, nullptr, ln);
+        SEG3D_CHECK_LAUNCH();
+        return SEG3D_OK;
+    }
     if (io == 1 || io == 2) {  // bf16-storage variants (sparse convs only)
         if (nbr == nullptr) return SEG3D_EINVAL;
         if (io == 1)
             hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 1>), grid, dim3(256), 0, st, x, nbr, m_out,
-                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
+                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr, LnEpilogue{nullptr, nullptr, 0.f});
         else
             hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 2>), grid, dim3(256), 0, st, x, nbr, m_out,
-                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
+                               reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr, LnEpilogue{nullptr, nullptr, 0.f});
         SEG3D_CHECK_LAUNCH();
         return SEG3D_OK;
     }
     if (nbr == nullptr && io == 4)  // Linear layer whose output is multiplied elementwise by `addend` (IO = 4)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 4>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr, LnEpilogue{nullptr, nullptr, 0.f});
     else if (nbr == nullptr && x_add)  // Linear layer with a second summand on the A operand (IO = 3)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 3>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, x_add);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, x_add, LnEpilogue{nullptr, nullptr, 0.f});
     else if (nbr == nullptr)  // Linear layer: own instantiation (own symbol in profiles, no table code)
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, nullptr, cin, cout, y, relu, nullptr, LnEpilogue{nullptr, nullptr, 0.f});
     else if (NBT <= kDeepMaxNbt && conv_depth2())  // narrow sparse layers: two chunks in flight
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false, 0, (NBT <= kDeepMaxNbt ? 2 : 1)>), grid, dim3(256), 0, st, x, nbr,
-                           m_out, reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
+                           m_out, reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr, LnEpilogue{nullptr, nullptr, 0.f});
     else
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, false>), grid, dim3(256), 0, st, x, nbr, m_out,
-                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr);
+                           reinterpret_cast<const uint4*>(wp), bias, addend, row_order, cin, cout, y, relu, nullptr, LnEpilogue{nullptr, nullptr, 0.f});
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -536,9 +595,9 @@ extern "C" int seg3d_debug_set_conv_nbt(int32_t nbt) {
     return SEG3D_OK;
 }
 
-int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
-                        const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
-                        hipStream_t st, const float* x_add) {
+static int split_fwd_impl(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                          const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
+                          hipStream_t st, const float* x_add, LnEpilogue ln) {
     if (x_add && (nbr || io != 0)) return SEG3D_EINVAL;  // the second summand exists for Linear layers only
     if (io == 4 && (nbr || !addend)) return SEG3D_EINVAL;  // ... and so does the elementwise factor
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deepest level has few rows
@@ -554,15 +613,26 @@ int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const 
     else if (nb % 3 == 0) pick = 3;
     else if (nb % 2 == 0) pick = 2;
     if (const int w = g_forced_nbt.load(std::memory_order_relaxed); w > 0 && nb % w == 0) pick = w;
-    switch (pick) {
-        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
-        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
-        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
-        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
-        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
-        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
-        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add);
+    if (io == 5) {  // one column group: the width is the row
+        if (nb != 1 && nb != 2 && nb != 3 && nb != 4 && nb != 6 && nb != 8 && nb != 12) return SEG3D_EINVAL;
+        pick = nb;
     }
+    switch (pick) {
+        case 12: return launch_split<12, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+        case 8: return launch_split<8, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+        case 6: return launch_split<6, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+        case 4: return launch_split<4, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+        case 3: return launch_split<3, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+        case 2: return launch_split<2, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+        default: return launch_split<1, 2>(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add, ln);
+    }
+}
+
+int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
+                        const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
+                        hipStream_t st, const float* x_add) {
+    return split_fwd_impl(x, nbr, m_out, wp, bias, addend, row_order, cin, cout, y, relu, io, st, x_add,
+                          LnEpilogue{nullptr, nullptr, 0.f});
 }
 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
@@ -603,6 +673,21 @@ int seg3d_linear_fwd(const float* x, int64_t m, const void* w_packed, const floa
     if (m == 0) return SEG3D_OK;
     if (!x || !y) return SEG3D_EINVAL;
     return spconv_split_fwd(x, nullptr, m, w_packed, bias, addend, nullptr, cin, cout, y, 0, as_stream(stream));
+}
+
+// y = res + LayerNorm(x W^T + b) in one launch (inference): the encoder layer's out-projection + norm1 + residual and
+// fc2 + norm2 + residual (point_transformer_layer.py:289-298).  cout <= 192 (the row must fit one workgroup's column
+// blocks: 16, 32, 48, 64, 96, 128 or 192 columns); SEG3D_EINVAL otherwise -- the caller runs the two passes.
+int seg3d_linear_layernorm_fwd(const float* x, int64_t m, const void* w_packed, const float* bias, const float* res,
+                               const float* gamma, const float* beta, float eps, int32_t cin, int32_t cout, float* y,
+                               void* stream) {
+    if (m < 0 || cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15) || !w_packed || !gamma || !beta) return SEG3D_EINVAL;
+    const int nb = cout / 16;
+    if (nb != 1 && nb != 2 && nb != 3 && nb != 4 && nb != 6 && nb != 8 && nb != 12) return SEG3D_EINVAL;
+    if (m == 0) return SEG3D_OK;
+    if (!x || !y) return SEG3D_EINVAL;
+    return split_fwd_impl(x, nullptr, m, w_packed, bias, res, nullptr, cin, cout, y, 0, 5, as_stream(stream), nullptr,
+                          LnEpilogue{gamma, beta, eps});
 }
 
 // y = (x W^T) * factor, elementwise: the input gradient of fc2 times the saved GELU derivative (point_transformer_layer.py:

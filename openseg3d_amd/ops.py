@@ -799,6 +799,17 @@ def _linear_apply_f32(x, packed, bias, cin, cout):
     return y
 
 
+LINEAR_LN_FUSED = os.environ.get("SEG3D_LINEAR_LN", "1") != "0"  # 0 = inference encoder layers run Linear and LayerNorm apart
+
+
+def _linear_layernorm(x, packed, bias, res, gamma, beta, eps, cin, cout):
+    """res + LayerNorm(x W^T + b) in one launch (inference; cout <= 192)."""
+    y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
+    _lib.call("seg3d_linear_layernorm_fwd", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta),
+              float(eps), cin, cout, _ptr(y), _stream())
+    return y
+
+
 def _linear_apply(x, packed, bias, cin, cout, addend=None):
     y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
     _lib.call("seg3d_linear_fwd", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), _ptr(addend), cin, cout, _ptr(y), _stream())
@@ -1547,9 +1558,16 @@ class _EncoderLayerFn(torch.autograd.Function):
         qk, v = _AttnInProjFn.forward(c_in, x, pos, w_in, b_in)
         c_at = _Ctx(True, True, True, False, False, False)
         o = _WindowAttnPackedFn.forward(c_at, qk, v, tau, tau_min, heads, wi, drop_p, drop_seed)
-        a = _linear_apply(o, _linear_pack(w_out, 0), b_out, c, c)
+        # inference: out-projection + LayerNorm + residual (and fc2 + LayerNorm + residual below) are ONE launch each --
+        # the normalised row fits a workgroup's column blocks up to C = 192 (seg3d_linear_layernorm_fwd)
+        fuse_ln = (LINEAR_LN_FUSED and not live and s1 is None and s2 is None and (c // 16) in (1, 2, 3, 4, 6, 8, 12)
+                   and b_out is not None and b2 is not None)
         c_n1 = _Ctx(True, True, True, True, False, False)
-        x1 = _LayerNormResidualFn.forward(c_n1, a, x, g1, be1, eps1, s1)
+        if fuse_ln:
+            x1 = _linear_layernorm(o, _linear_pack(w_out, 0), b_out, x, g1, be1, eps1, c, c)
+        else:
+            a = _linear_apply(o, _linear_pack(w_out, 0), b_out, c, c)
+            x1 = _LayerNormResidualFn.forward(c_n1, a, x, g1, be1, eps1, s1)
         hid = w1.shape[0]
         h = _linear_apply(x1, _linear_pack(w1, 0), b1, c, hid)
         if live and GELU_SAVED_GRAD:
@@ -1560,9 +1578,12 @@ class _EncoderLayerFn(torch.autograd.Function):
             h = gp
         else:
             g = torch.nn.functional.gelu(h)
-        m = _linear_apply(g, _linear_pack(w2, 0), b2, hid, c)
         c_n2 = _Ctx(True, True, True, True, False, False)
-        x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
+        if fuse_ln:
+            x2 = _linear_layernorm(g, _linear_pack(w2, 0), b2, x1, g2, be2, eps2, hid, c)
+        else:
+            m = _linear_apply(g, _linear_pack(w2, 0), b2, hid, c)
+            x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
         ctx.parts = (c_in, c_at, c_n1, c_n2)
         ctx.save_for_backward(o, x1, h, g, w_out, w1, w2)
         ctx.bias_params = (b_out, b1, b2)

@@ -234,3 +234,34 @@ def test_gelu_with_derivative_and_multiplying_epilogue():
     assert torch.equal(fused, plain * gp)
     want = torch.ops.aten.gelu_backward(plain, h)
     assert float((fused - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("m,cin,cout", [(5000, 48, 48), (12345, 192, 96), (7000, 96, 96), (3001, 384, 192), (2500, 192, 192), (77, 16, 16)])
+def test_linear_with_layernorm_epilogue(m, cin, cout):
+    """seg3d_linear_layernorm_fwd (y = res + LayerNorm(x W^T + b), one launch: the inference encoder layer's out-projection +
+    norm1 + residual and fc2 + norm2 + residual) against the two library passes it replaces (same split products, LayerNorm
+    statistics summed in another order: 1e-5) and against float64; widths that do not fit one workgroup are refused."""
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m + cout)
+    x, res = torch.randn(m, cin, device=dev), torch.randn(m, cout, device=dev)
+    w, b = torch.randn(cout, cin, device=dev) / cin ** 0.5, torch.randn(cout, device=dev)
+    ln = torch.nn.LayerNorm(cout).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_()
+    packed = ops._linear_pack(w, 0)
+    for r in (res, None):
+        got = ops._linear_layernorm(x, packed, b, r, ln.weight, ln.bias, ln.eps, cin, cout)
+        with torch.no_grad():
+            two = ops.layer_norm_residual(ops._linear_apply(x, packed, b, cin, cout), r, ln)
+            ref = torch.nn.functional.layer_norm(x.double() @ w.double().t() + b.double(), (cout,), ln.weight.double(), ln.bias.double(), ln.eps)
+            ref = ref if r is None else ref + r.double()
+        assert float((got - two).abs().max()) < 1e-5 * max(1.0, float(two.abs().max()))
+        assert float((got.double() - ref).abs().max()) < 2e-4
+    y = torch.empty(m, 384, device=dev)
+    w2 = torch.randn(384, cin, device=dev)
+    with pytest.raises(_lib.Seg3dError):
+        _lib.call("seg3d_linear_layernorm_fwd", ops._ptr(x), m, ops._ptr(ops._linear_pack(w2, 0)), ops._ptr(None), ops._ptr(None),
+                  ops._ptr(torch.ones(384, device=dev)), ops._ptr(torch.zeros(384, device=dev)), 1e-5, cin, 384, ops._ptr(y),
+                  ops._stream())

@@ -22,7 +22,8 @@ def main():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-            cur, vals = name.split("(anonymous namespace)::")[-1].split("(")[0][:60], {}
+            # kernel name without its namespace and parameter list (parameters may name anonymous-namespace types too)
+            cur, vals = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60], {}
             continue
         for key, short in KEYS.items():
             if key in line and "Spill" not in line and "Total" not in line:
