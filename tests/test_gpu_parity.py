@@ -819,3 +819,25 @@ def test_class_context_matches_the_reference_loop(dev, rows):
     again = ops.class_context(fg, pg, offsets, scale)
     again.backward(g.to(dev))
     assert torch.equal(first[0], again) and torch.equal(first[1], fg.grad) and torch.equal(first[2], pg.grad)
+
+
+def test_opt_in_conv_schedules_change_no_bit(dev, tmp_path):
+    """The gather-GEMM's opt-in schedules -- submanifold rows grouped by neighbour mask (SEG3D_SUBM_ORDER) and two chunks in
+    flight on the narrow layers (SEG3D_CONV_DEPTH=2), both measured slower and off by default -- reorder work, never
+    arithmetic: forward, input gradient and weight gradient of three layers are bit-identical to the default schedule's.
+    (The switches are read at import / library load, hence child processes.)"""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_conv_switch_child.py")
+    outs = {}
+    for tag, env in (("default", {}), ("grouped", {"SEG3D_SUBM_ORDER": "512", "SEG3D_CONV_DEPTH": "2"}),
+                     ("one_bucket", {"SEG3D_SUBM_ORDER": "-1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        run = subprocess.run([sys.executable, child, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs[tag] = torch.load(path)
+    assert int(outs["default"]["order0"]) == 0 and int(outs["grouped"]["order0"]) > 0
+    for tag in ("grouped", "one_bucket"):
+        for k, v in outs["default"].items():
+            if not k.startswith("order"):
+                assert torch.equal(v, outs[tag][k]), (tag, k)
