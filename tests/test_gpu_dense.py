@@ -6,7 +6,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("m,cin,cout", [(1000, 48, 96), (4097, 64, 64), (31, 192, 384), (70000, 96, 192),
-                                        (513, 104, 48), (5000, 256, 64), (64, 768, 384)])
+                                        (513, 104, 48), (5000, 256, 64), (64, 768, 384),
+                                        # the wide kernel's block shapes: 2 x 3, 3 x 2, 2 x 2 waves, ragged last steps
+                                        (40001, 192, 384), (33333, 384, 192), (20011, 384, 384), (9999, 384, 768),
+                                        (20000, 768, 384), (12345, 128, 256)])
 def test_linear_wgrad_matches_autograd(m, cin, cout):
     from openseg3d_amd import ops
     dev = torch.device("cuda:0")
