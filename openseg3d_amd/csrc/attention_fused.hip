@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
     const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min,
-    float* __restrict__ out, float* __restrict__ lse, DropoutParams drop, int xcd_groups) {
+    float* __restrict__ out, float* __restrict__ lse, DropoutParams drop, int xcd_groups, int xcd_block) {
     using C = Cfg<DH>;
     using F = FwdGeo<DH>;
     constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW, NB = C::NB;
@@ -117,11 +117,11 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
     const int XG = xcd_groups;                  // 1 = flat order
     const int gx = (int)blockIdx.x % XG, gs = (int)blockIdx.x / XG;
     const int S = ((int)gridDim.x - gx + XG - 1) / XG;       // workgroups of my group
-    const int units_x = ((n_items - gx + XG - 1) / XG) * hgn;  // units of my group: u = s + j * S
+    const int units_x = xcd_block_count(n_items, gx, XG, xcd_block) * hgn;  // units of my group: u = s + j * S
     const int J = units_x > gs ? (units_x - gs + S - 1) / S : 0;
     auto unit_of = [&](int j, int* item, int* hg) {
         const int u = gs + j * S;
-        *item = (u / hgn) * XG + gx;
+        *item = xcd_block_item(u / hgn, gx, XG, xcd_block);  // blocks of consecutive items (one window's tiles) per XCD
         *hg = u % hgn;
     };
     const float qscale = kLog2e / fmaxf(tau[0], tau_min);
@@ -590,15 +590,16 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
     const long long total = (long long)n_items * (heads / C::HG);
     static const int xcd_env = getenv("SEG3D_ATTN_XCD") ? atoi(getenv("SEG3D_ATTN_XCD")) : 8;  // A/B: 1 = flat order
     const int xg = xcd_env > 0 ? xcd_env : 8;
+    const int xb = xg == 1 ? 1 : xcd_block_items(C::kNarrow);
     long long wgs = total < (long long)n_cu * per_cu ? total : (long long)n_cu * per_cu;
     wgs = (wgs + xg - 1) / xg * xg;  // whole groups (a workgroup without units returns at once)
     const dim3 grid((unsigned)wgs);
     if (drop.threshold)
         hipLaunchKernelGGL((attn_fused_fwd<DH, true>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, tok, win_start, win_count,
-                           items, n_items, heads, tau, tau_min, out, lse, drop, xg);
+                           items, n_items, heads, tau, tau_min, out, lse, drop, xg, xb);
     else
         hipLaunchKernelGGL((attn_fused_fwd<DH, false>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, tok, win_start, win_count,
-                           items, n_items, heads, tau, tau_min, out, lse, drop, xg);
+                           items, n_items, heads, tau, tau_min, out, lse, drop, xg, xb);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }

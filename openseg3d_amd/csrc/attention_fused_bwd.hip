@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
     const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
     int lddq, float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, float* __restrict__ tau_part,
-    float* __restrict__ delta_buf, DropoutParams drop) {
+    float* __restrict__ delta_buf, DropoutParams drop, int xcd_block) {
     using C = Cfg<DH>;
     constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW;
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     constexpr int XG = 8;
     const int hgn = heads / HG;
     const int gx = (int)blockIdx.x % XG, gu = (int)blockIdx.x / XG;
-    const int item_i = (gu / hgn) * XG + gx;
+    const int item_i = xcd_block_item(gu / hgn, gx, XG, xcd_block);  // blocks of consecutive items per XCD (attn_fused.hpp)
     if (item_i >= n_items) {  // (padding of the last group)
         if (MODE == 0 && tau_part && lane == 0) tau_part[(size_t)blockIdx.x * 4 + wave] = 0.f;
         return;
@@ -621,7 +621,10 @@ __global__ __launch_bounds__(1024) void tau_reduce_fused(const float* __restrict
 }
 
 // blocks of a pass: whole groups of 8 items x head groups (the kernel's block -> (item, head group) map)
-static size_t bwd_blocks(int n_items, int hgn) { return (size_t)((n_items + 7) / 8) * 8 * hgn; }
+static size_t bwd_blocks(int n_items, int hgn, int xb) {
+    const size_t per = (size_t)8 * xb;
+    return (n_items + per - 1) / per * per * hgn;
+}
 
 template <int DH>
 int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out, const float* dout,
@@ -632,14 +635,15 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
     using C = Cfg<DH>;
     const int2* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
-    const dim3 grid((unsigned)(bwd_blocks(n_items, heads / C::HG)));
+    const int xb = xcd_block_items(C::kNarrow);
+    const dim3 grid((unsigned)(bwd_blocks(n_items, heads / C::HG, xb)));
     hipLaunchKernelGGL((attn_fused_bwd<DH, 0>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
-                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, delta_buf, drop);
+                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, delta_buf, drop, xb);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(tau_reduce_fused, dim3(1), dim3(1024), 0, st, tau_part, (int)(grid.x * 4), dtau);
     SEG3D_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_fused_bwd<DH, 1>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
-                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, delta_buf, drop);
+                       win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, nullptr, delta_buf, drop, xb);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -655,7 +659,7 @@ bool attn_fused_bwd_supported(int heads, int dh) {
 }
 
 static size_t tau_part_bytes(int n_tiles, int n_chunks, int heads, int dh) {
-    const size_t blocks = (dh <= 12) ? bwd_blocks(n_tiles, heads / 4) : bwd_blocks(n_chunks, heads);
+    const size_t blocks = (dh <= 12) ? bwd_blocks(n_tiles, heads / 4, xcd_block_items(true)) : bwd_blocks(n_chunks, heads, xcd_block_items(false));
     return align_up(blocks * 4 * sizeof(float), 256);
 }
 

@@ -1,6 +1,7 @@
 // Geometry and helpers shared by the fused window-attention kernels (attention_fused.hip: forward,
 // attention_fused_bwd.hip: the two backward passes).  See attention_fused.hip for the design.
 #pragma once
+#include <cstdlib>
 #include "attn_common.hpp"
 #include "attn_dropout.hpp"
 
@@ -51,6 +52,29 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t* hi, uint32_t*
     const uint32_t w = pack_bf16(a, b);
     *hi = w;
     *lo = pack_bf16(a - __builtin_bit_cast(float, w << 16), b - __builtin_bit_cast(float, w & 0xFFFF0000u));
+}
+
+// Work items are dealt to the 8 XCDs in BLOCKS of consecutive items (items are sorted by window: the 32-token tiles /
+// 128-token chunks of one window are neighbours in the list and stream the SAME key / value rows, so they belong on one
+// L2).  Item of the q-th item slot of group gx:  ((q / B) * XG + gx) * B + q % B.  Measured fabric traffic of the forward
+// with single items dealt round-robin (B = 1): 1.5 - 2.7 x the footprint of q | k | v and the output (tools/collect_attn_traffic.sh).
+__host__ __device__ __forceinline__ int xcd_block_item(int q, int gx, int xg, int b) { return ((q / b) * xg + gx) * b + q % b; }
+// item slots of group gx that hold a real item (the list's last, partial block belongs to one group and sits at its end)
+__host__ __device__ __forceinline__ int xcd_block_count(int n_items, int gx, int xg, int b) {
+    const int nb = (n_items + b - 1) / b;               // blocks in the list
+    const int mine = nb > gx ? (nb - gx + xg - 1) / xg : 0;  // blocks of this group
+    if (mine == 0) return 0;
+    const int last = nb - 1;
+    return mine * b - (last % xg == gx ? nb * b - n_items : 0);
+}
+// items per block: SEG3D_ATTN_XCD_BLOCK (A/B).  Default 1 = single items round-robin: measured on the headline scene,
+// forward + backward with dropout 8.35 - 8.40 ms at 1, 8.33 - 8.36 at 2 and 4 (within the run-to-run spread), 8.5 at 8 - 16,
+// 8.85 at 32 (whole windows on one XCD unbalance the groups; stage 4 with its 242 items loses 8 % already at 4).  The
+// kernels move 2 - 4.5 TB/s over the fabric and are not bound by it.
+inline int xcd_block_items(bool narrow) {
+    static const int env = getenv("SEG3D_ATTN_XCD_BLOCK") ? atoi(getenv("SEG3D_ATTN_XCD_BLOCK")) : 0;
+    (void)narrow;
+    return env > 0 ? env : 1;
 }
 
 }  // namespace attn_fused

@@ -17,6 +17,7 @@ P=gpurun_out/r3p; S=$P/summaries; mkdir -p $S
 python3 tools/pmc_derived.py $P/pmc_a/*/ $P/pmc_b/*/ 'attn_' > $S/pmc_attention.txt 2>&1
 python3 tools/pmc_derived.py $P/pmc_a/*/ $P/pmc_b/*/ 'spconv_split|wgrad' > $S/pmc_conv.txt 2>&1
 python3 tools/pmc_conv_traffic.py $P/fetch/*/*_counter_collection.csv $P/write/*/*_counter_collection.csv $P/layers_fetch.json $S/pmc_conv_traffic.json > $S/pmc_conv_traffic.log 2>&1
+python3 tools/pmc_kernel_traffic.py $P/fetch/*/*_counter_collection.csv $P/write/*/*_counter_collection.csv 'attn_fused_fwd' > $S/pmc_attention_traffic.txt 2>&1
 python3 tools/trace_summary.py $P/one_stream/*/*_kernel_trace.csv --steps 6 --csv $S/train_step_kernels.csv > $S/train_step_kernels.txt 2>&1
 python3 tools/trace_summary.py $P/default/*/*_kernel_trace.csv --steps 6 --csv $S/train_step_kernels_shipped_streams.csv > $S/train_step_kernels_shipped_streams.txt 2>&1
 cp $P/fwd/*/*_kernel_stats.csv $S/bench_fwd_kernel_stats.csv; cp $P/default/*/*_kernel_stats.csv $S/bench_default_kernel_stats.csv; cp $P/one_stream/*/*_kernel_stats.csv $S/bench_one_stream_kernel_stats.csv
