@@ -85,20 +85,20 @@ def conv_roofline(model, batch, dev):
     records = []
     orig = ops._conv_apply
 
-    def timed(x, nbr, w_packed, bias, cin, cout, order=None):  # noqa: E306
+    def timed(x, nbr, w_packed, bias, cin, cout, order=None, plan=None):  # noqa: E306
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig(x, nbr, w_packed, bias, cin, cout, order)
+        y = orig(x, nbr, w_packed, bias, cin, cout, order, plan)
         e1.record()
         records.append((nbr, cin, cout, e0, e1, x.shape[0], x.element_size(), y.element_size()))
         return y
 
     orig_act = ops.conv_act  # inference form of the conv blocks (BatchNorm folded, ReLU / residual in the epilogue)
 
-    def timed_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True):  # noqa: E306
+    def timed_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True, plan=None):  # noqa: E306
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig_act(x, nbr, packed, bias, cin, cout, order, addend, relu)
+        y = orig_act(x, nbr, packed, bias, cin, cout, order, addend, relu, plan)
         e1.record()
         records.append((nbr, cin, cout, e0, e1, x.shape[0], x.element_size(), y.element_size()))
         return y

@@ -193,6 +193,25 @@ int seg3d_spconv_fwd_presplit(const void* xs, const int32_t* nbr, int64_t m_out,
                               int32_t pack_flags, const float* bias /*or NULL*/, const float* addend /*or NULL*/,
                               int32_t relu, int32_t cin, int32_t cout, float* y,
                               const int32_t* row_order /*or NULL*/, void* stream);
+/* a9 "row image" schedule of the same gather-GEMM for submanifold tables (spconv.SubMConv3d, call sites
+ * seg3d/utils/spconv_utils.py:15-17, seg3d/models/backbones/pointtransformer.py:26-34,47-66,88-113; spconv builds the
+ * equivalent "indice pairs" once per indice_key and reuses them in every layer that names the key).  A TILE PLAN is built
+ * once per neighbour table (site level): output rows in Morton order of their coordinates, 128 per tile, inside a tile
+ * sorted by neighbour mask; per tile the list of DISTINCT input rows (<= 512, else the tile runs offset by offset) and,
+ * per (offset, row), the LDS slot of the neighbour's row.  seg3d_spconv_fwd_tiled then loads and splits every distinct
+ * input row of a tile ONCE per 32-channel slice into an LDS image and feeds all 27 offsets from it (spconv_split gathers and
+ * splits per (row, offset) pair: 6.5 - 17 times per row).  Results are bit-identical to seg3d_spconv_fwd_act on the same
+ * operands (same products in the same order per output row).  coords [m_out, 4] (b, z, y, x) int32 are the sites the
+ * table's rows belong to; nbr [27][m_out] may gather from any row set (m_in rows).  cout % 32 == 0 or cout % 48 == 0
+ * (seg3d_spconv_tiled_supported), split-bf16 packs only; forward and dgrad (W^T pack, flipped offsets) share one plan. */
+size_t seg3d_conv_plan_bytes(int64_t m_out);
+size_t seg3d_conv_plan_workspace_bytes(int64_t m_out);
+int seg3d_conv_plan_build(const int32_t* coords, const int32_t* nbr, int64_t m_out, void* plan, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int32_t seg3d_spconv_tiled_supported(int32_t cin, int32_t cout);
+int seg3d_spconv_fwd_tiled(const float* x, const int32_t* nbr, const void* plan, int64_t m_out, int64_t m_in,
+                           const void* w_packed, int32_t pack_flags, const float* bias /*or NULL*/,
+                           const float* addend /*or NULL*/, int32_t relu, int32_t cin, int32_t cout, float* y, void* stream);
 /* Test hook: force the column-block width (x16 columns) of the split-bf16 gather-GEMM so that every kernel
  * instantiation can be pinned against the oracle at any row count (0 = automatic choice; 1, 2, 3, 4, 6, 12).
  * Same effect as the SEG3D_CONV_NBT environment variable, which is read once when the library loads.

@@ -439,6 +439,40 @@ def rulebook_subm(h):
     return nbr
 
 
+# a9 "row image" schedule of the submanifold convs (csrc/spconv_tile.hip): 0 = off, 1 = every layer the schedule takes.
+# SEG3D_CONV_TILED_MIN_C: smallest max(cin, cout) that takes it (narrower layers keep the per-pair gather).
+CONV_TILED = os.environ.get("SEG3D_CONV_TILED", "1") != "0"
+CONV_TILED_MIN_C = int(os.environ.get("SEG3D_CONV_TILED_MIN_C", "0"))
+
+
+class ConvPlan:
+    """Tile plan of one neighbour table (seg3d_conv_plan_build): Morton-ordered 128-row tiles with their distinct input
+    rows and per-(offset, row) image slots.  Built once per site level, used by every layer on it, forward and dgrad."""
+
+    def __init__(self, coords, nbr):
+        _need_gpu(coords, nbr)
+        coords = _i32c(coords)
+        m = nbr.shape[1]
+        if coords.shape[0] != m or nbr.shape[0] != 27 or nbr.dtype != torch.int32 or not nbr.is_contiguous():
+            raise _lib.Seg3dError("ConvPlan: coords [m, 4] and a contiguous int32 table [27, m] of the same sites expected")
+        self.nbr, self.m = nbr, m
+        self.data = torch.empty((max(_lib.query("seg3d_conv_plan_bytes", m), 1),), dtype=torch.uint8, device=nbr.device)
+        ws_bytes = _lib.query("seg3d_conv_plan_workspace_bytes", m)
+        ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=nbr.device)
+        _lib.call("seg3d_conv_plan_build", _ptr(coords), _ptr(nbr), m, _ptr(self.data), _ptr(ws), ws_bytes, _stream())
+
+
+def _tiled_fits(plan, packed, cin, cout):
+    return (plan is not None and CONV_TILED and bool(packed.flags & PACK_SPLIT_BF16) and max(cin, cout) >= CONV_TILED_MIN_C
+            and bool(_lib.load().seg3d_spconv_tiled_supported(int(cin), int(cout))))
+
+
+def _conv_tiled(x, plan, packed, bias, addend, relu, cin, cout, y):
+    _lib.call("seg3d_spconv_fwd_tiled", _ptr(x), _ptr(plan.nbr), _ptr(plan.data), plan.m, x.shape[0], _ptr(packed.data),
+              packed.flags, _ptr(bias), _ptr(addend), int(bool(relu)), cin, cout, _ptr(y), _stream())
+    return y
+
+
 def downsample_launch(coords, batch_size, spatial_shape, rows_dev=None):
     """Queue the output-site build of SparseConv3d(k=3, s=2, p=1) without reading anything back: returns (buffer [cap, 4],
     count int32 [1] on the device, shape_out).  ``rows_dev``: device count of valid rows when ``coords`` is itself such a
@@ -661,9 +695,11 @@ def _conv_dma(x, nbr, packed, bias, addend, relu, cin, cout, order, y):
     return y
 
 
-def _conv_apply(x, nbr, packed, bias, cin, cout, order=None):
+def _conv_apply(x, nbr, packed, bias, cin, cout, order=None, plan=None):
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
+    if _tiled_fits(plan, packed, cin, cout):
+        return _conv_tiled(x, plan, packed, bias, None, False, cin, cout, y)
     if _conv_dma_fits(packed, cin, cout):
         return _conv_dma(x, nbr, packed, bias, None, False, cin, cout, order, y)
     _lib.call("seg3d_spconv_fwd", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
@@ -687,7 +723,7 @@ def conv_storage_bf16():
     return STORAGE == "bf16" and CONV_PRECISION == "bf16x3" and not torch.is_grad_enabled()
 
 
-def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True):
+def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True, plan=None):
     """act(conv(x) + bias (+ addend)) in one launch (inference form of a conv block, seg3d_spconv_fwd_act); in the bf16
     storage mode the output (and the residual it adds) is bf16, the input float32 or bf16 as it comes."""
     if conv_storage_bf16() and not _conv_dma_fits(packed, cin, cout):
@@ -709,6 +745,8 @@ def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True
     m_out = nbr.shape[1]
     y = torch.empty((m_out, cout), dtype=torch.float32, device=x.device)
     addend = None if addend is None else _f32c(addend)
+    if _tiled_fits(plan, packed, cin, cout):
+        return _conv_tiled(x, plan, packed, bias, addend, relu, cin, cout, y)
     if _conv_dma_fits(packed, cin, cout):
         return _conv_dma(x, nbr, packed, bias, addend, relu, cin, cout, order, y)
     _lib.call("seg3d_spconv_fwd_act", _ptr(x), _ptr(nbr), m_out, x.shape[0], _ptr(packed.data), packed.flags, _ptr(bias),
@@ -720,14 +758,15 @@ class _SparseConvFn(torch.autograd.Function):
     """y[r] = bias + sum_k x[nbr[k][r]] . W_k ; nbr_t is the same pair list keyed by input row."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t):
+    def forward(ctx, x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t, plan=None, plan_t=None):
         x = _f32c(x)
         cout, cin = weight.shape[0], weight.shape[-1]
         if packed is None:
             packed = pack_weight(weight, PACK_FWD)
-        y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout, order)
+        y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout, order, plan)
         ctx.save_for_backward(x, weight)
         ctx.nbr, ctx.nbr_t, ctx.t_flags, ctx.has_bias, ctx.order_t = nbr, nbr_t, t_flags, bias is not None, order_t
+        ctx.plan_t = plan_t
         ctx.bias_param = bias
         return y
 
@@ -746,7 +785,7 @@ class _SparseConvFn(torch.autograd.Function):
                       _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, fk.fork(ws, dy, x, ctx.nbr))
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight, ctx.t_flags)
-            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t)
+            dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t, ctx.plan_t)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if fk.on:  # a parameter gradient like dw: column sums of dy on the side stream
                 fk.fork(dy)
@@ -755,14 +794,15 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 db = dy.sum(0)
         fk.join((weight, dw), (ctx.bias_param, db))
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None, order=None, order_t=None):
+def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None, order=None, order_t=None, plan=None, plan_t=None):
     """order / order_t: optional processing orders (int32 permutations) of the rows of nbr / nbr_t -- see
-    SiteLevel.parity_order; they change scheduling only, never results."""
+    SiteLevel.parity_order; plan / plan_t: optional tile plans (ConvPlan) of nbr / nbr_t -- see SiteLevel.subm_plan.
+    They change scheduling only, never results."""
     _need_gpu(x, weight, nbr)
-    return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t)
+    return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t, plan, plan_t)
 
 
 # ------------------------------------------------------------------------------------------ a6/a22 dense layers

@@ -202,6 +202,7 @@ class PointTransformer(nn.Module):
         for k in range(4):
             level.subm()
             level.mask_order()
+            level.subm_plan()
             part = getattr(self, f"swformer_block{k + 1}")[0]
             if part not in level.window_plans:  # partition kernels queued now, counts of all stages read back once below
                 level.window_plans[part] = part.launch_plan(level.coords, level.batch_size, widths[k])

@@ -47,6 +47,7 @@ class SiteLevel:
         self._down = None
         self._parity = None
         self._mask_order = None
+        self._subm_plan = None
         self._coarse = None  # [(coords, shape)] of the following strided levels when seeded by seed_chain()
         self._offsets = False
         self.window_plans = {}  # SparseWindowPartitionLayer -> WindowPlan of this level (built once per forward)
@@ -77,6 +78,16 @@ class SiteLevel:
         if self._subm is None:
             self._subm = ops.rulebook_subm(self.hash)
         return self._subm
+
+    def subm_plan(self):
+        """Tile plan of the submanifold table (ops.ConvPlan; None when the tiled schedule is switched off): Morton-ordered
+        128-row tiles, their distinct input rows and image slots.  Built once, shared by every SubMConv3d on this level,
+        forward and input gradient (the transposed table is the same table with the offsets mirrored)."""
+        if not ops.CONV_TILED or ops.CONV_PRECISION != "bf16x3" or self.coords.shape[0] == 0:
+            return None
+        if self._subm_plan is None:
+            self._subm_plan = ops.ConvPlan(self.coords, self.subm())
+        return self._subm_plan
 
     def mask_order(self):
         """Processing order of the submanifold table's rows (int32 [M]; None = table order): inside buckets of
@@ -182,12 +193,17 @@ class _Conv3x3x3(SparseModule):
                 self._packed = (key, ops.pack_weight(w, ops.PACK_FWD))
         return self._packed[1]
 
-    def _apply_tables(self, feats, nbr, nbr_t, t_flags, order=None, order_t=None):
+    def _apply_tables(self, feats, nbr, nbr_t, t_flags, order=None, order_t=None, plan=None, plan_t=None):
         if self._pad_in:
             feats = torch.nn.functional.pad(feats, (0, self._pad_in))
             weight = torch.nn.functional.pad(self.weight, (0, self._pad_in))
-            return ops.sparse_conv(feats, weight, self.bias, nbr, nbr_t, t_flags, None, order, order_t)
-        return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight(), order, order_t)
+            return ops.sparse_conv(feats, weight, self.bias, nbr, nbr_t, t_flags, None, order, order_t, plan, plan_t)
+        return ops.sparse_conv(feats, self.weight, self.bias, nbr, nbr_t, t_flags, self._packed_weight(), order, order_t,
+                               plan, plan_t)
+
+    def plans(self, x):
+        """(tile plan of tables()'s nbr, of its nbr_t) or (None, None): see SiteLevel.subm_plan."""
+        return None, None
 
     def tables(self, x):
         """(nbr [27, rows_out], nbr_t, pack flags of the transposed operand, row order, row order of nbr_t, output
@@ -196,7 +212,8 @@ class _Conv3x3x3(SparseModule):
 
     def forward(self, x):
         nbr, nbr_t, t_flags, order, order_t, level = self.tables(x)
-        return x.on_level(self._apply_tables(x.features, nbr, nbr_t, t_flags, order, order_t), level)
+        plan, plan_t = self.plans(x)
+        return x.on_level(self._apply_tables(x.features, nbr, nbr_t, t_flags, order, order_t, plan, plan_t), level)
 
     def fusable_with(self, bn, x):
         """Inference only: conv -> BatchNorm(eval) -> (+ residual) -> ReLU can run as one launch."""
@@ -217,7 +234,8 @@ class _Conv3x3x3(SparseModule):
                 self._folded = (key, ops.pack_weight(wf, ops.PACK_FWD, use_registry=False), bf.contiguous())
         _, packed, bias = self._folded
         nbr, _, _, order, _, level = self.tables(x)
-        y = ops.conv_act(x.features, nbr, packed, bias, self.in_channels, self.out_channels, order, addend=res, relu=relu)
+        y = ops.conv_act(x.features, nbr, packed, bias, self.in_channels, self.out_channels, order, addend=res, relu=relu,
+                         plan=self.plans(x)[0])
         return x.on_level(y, level)
 
     def extra_repr(self):
@@ -230,6 +248,10 @@ class SubMConv3d(_Conv3x3x3):
         nbr = x.level.subm()
         order = x.level.mask_order()  # (the transposed table is the same table with the offsets mirrored: same grouping)
         return nbr, nbr, ops.PACK_T_FLIP, order, order, x.level
+
+    def plans(self, x):
+        plan = x.level.subm_plan()
+        return plan, plan
 
 
 class SparseConv3d(_Conv3x3x3):

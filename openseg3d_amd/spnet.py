@@ -169,6 +169,7 @@ class SparseUnet(nn.Module):
         for k in range(4):
             level.subm()
             level.mask_order()
+            level.subm_plan()
             if k >= 2:
                 level.sample_offsets()  # squeeze-excite of conv3 / conv4, OCR
             if k < 3:
