@@ -25,6 +25,7 @@
 // "direct": the image is refilled per offset with that offset's 128 neighbour rows.
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -237,13 +238,18 @@ __global__ __launch_bounds__(kThreads) void plan_kernel(const uint32_t* __restri
 
 // ------------------------------------------------------------------------------------------------ the conv
 // WR x WC = 4 waves: WR row groups of 128 / WR rows, WC column groups of NBW x 16 columns.
-template <int WR, int WC, int NBW>
+// KS (narrow layers, the workgroup's columns are all of cout <= 64): the four waves share ONE 128-row x cout tile and
+// split its chunks (every 4th active offset of a slice each) instead of its rows -- 72 MFMAs per wave and chunk against
+// one set of B loads instead of 18, and no wave loads a B fragment another wave loads too; the four partial tiles are
+// summed through LDS in a fixed order at the end (so this layout is deterministic but not bit-identical to the per-pair
+// gather kernel, whose rows accumulate offset by offset).
+template <int WR, int WC, int NBW, bool KS = false>
 __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
                                                                   PlanView pv, int64_t m_out, int n_tiles, int n_cg,
                                                                   const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                   const float* __restrict__ addend, int cin, int cout,
-                                                                  float* __restrict__ y, int relu) {
-    static_assert(WR * WC == 4, "four waves");
+                                                                  float* __restrict__ y, int relu, int dbg) {
+    static_assert(KS ? (WR == 1 && WC == 1 && NBW <= 3) : (WR * WC == 4), "four waves");
     constexpr int RB = 8 / WR;  // 16-row blocks per wave
     __shared__ __attribute__((aligned(16))) u32x4 img[(kUMax + 1) * 8];
     __shared__ __attribute__((aligned(16))) uint16_t lidx_s[27 * kTile];
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int wr = wave / WC, wc = wave % WC;
+    const int wr = KS ? 0 : wave / WC, wc = KS ? 0 : wave % WC;
     // workgroups of one tile (its column groups) sit on one XCD (blockIdx % 8), side by side in launch order
     const int grp = blockIdx.x / (8 * n_cg), rem = blockIdx.x % (8 * n_cg);
     const int cg = rem >> 3, tile = grp * 8 + (rem & 7);
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
     f32x4 acc[RB][NBW];
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-        const float b = bias ? bias[(nb0 + n) * 16 + c16] : 0.0f;
+        const float b = bias && (!KS || wave == 0) ? bias[(nb0 + n) * 16 + c16] : 0.0f;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb][n] = (f32x4){b, b, b, b};
     }
@@ -330,16 +336,17 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
     // fragments from register set S
     auto multiply = [&](auto S, uint32_t bmw, const uint32_t* li /* RB image slots of this lane's rows */) {
         if (bmw == 0u) return;
+        if (dbg & 8) bmw = (1u << RB) - 1u;
         bf16x8 a_hi[2], a_lo[2];
         {
-            const uint32_t s = li[0] ^ (uint32_t)g;
+            const uint32_t s = (dbg & 4) ? (uint32_t)lane : li[0] ^ (uint32_t)g;
             a_hi[0] = __builtin_bit_cast(bf16x8, img[s]);
             a_lo[0] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (rb + 1 < RB) {
-                const uint32_t s = li[rb + 1] ^ (uint32_t)g;
+                const uint32_t s = (dbg & 4) ? (uint32_t)(lane + 8 * rb) : li[rb + 1] ^ (uint32_t)g;
                 a_hi[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s]);
                 a_lo[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
             }
@@ -385,11 +392,31 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
                 li[1] = w >> 16;
             }
         };
+        uint32_t li[2][RB];
+        uint32_t bmw[2];
+        uint32_t itmask = tmask;  // the offsets this wave multiplies
+        if constexpr (KS) {       // every 4th active one
+            itmask = 0u;
+            uint32_t t = tmask;
+            for (int j = 0; t != 0u; ++j) {
+                const int k = __builtin_ctz(t);
+                t &= t - 1;
+                if ((j & 3) == wave) itmask |= 1u << k;
+            }
+            itmask = (uint32_t)__builtin_amdgcn_readfirstlane(itmask);
+        }
+        if (itmask == 0u) {  // (KS, fewer than four active offsets: nothing to multiply, but the image refills need every wave)
+            for (int cb = 0; cb < cb_n; ++cb) {
+                __syncthreads();
+                stage(cb, U, [&](int u) { return uniq_s[u]; });
+                __syncthreads();
+            }
+        } else {
         struct Chunk {
             int k, cb;
             bool have, first;
         };
-        uint32_t it_todo = tmask;
+        uint32_t it_todo = itmask;
         int it_cb = 0;
         bool it_first = true;
         auto next_chunk = [&]() {
@@ -399,7 +426,7 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
             it_first = false;
             if (it_todo == 0u) {
                 it_cb += 1;
-                it_todo = tmask;
+                it_todo = itmask;
                 c.have = it_cb < cb_n;
                 c.first = true;
             }
@@ -411,17 +438,15 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
         // One chunk: (refill the image at a slice boundary,) request the B fragments and the image slots of the NEXT chunk,
         // multiply the current one.  The next chunk's loads are issued unconditionally (past the end: the last chunk again)
         // so that the count of loads in flight is the same on every path and the compiler waits for exactly the current set.
-        uint32_t li[2][RB];
-        uint32_t bmw[2];
         auto run = [&](auto SC, auto SN, const Chunk& cur, Chunk& nxt) {
-            if (cur.first) {  // new 32-channel slice: every wave is done with the old image, refill it
+            if (cur.first && !((dbg & 1) && cur.cb > 0)) {  // new 32-channel slice: every wave is done with the old image, refill it
                 __syncthreads();
                 stage(cur.cb, U, [&](int u) { return uniq_s[u]; });
                 __syncthreads();
             }
             nxt = next_chunk();
             const int kn = nxt.have ? nxt.k : cur.k, cbn = nxt.have ? nxt.cb : cur.cb;
-            load_b(SN, kn, cbn);
+            if (!(dbg & 2)) load_b(SN, kn, cbn);
             slots_of(kn, li[SN]);
             bmw[SN] = block_mask(kn);
             multiply(SC, bmw[SC], li[SC]);
@@ -436,6 +461,7 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
             run(S1{}, S0{}, b, a);
             if (!a.have) break;
         }
+        }
     } else if (tmask != 0u) {
         // direct tile: the image holds the 128 neighbour rows of ONE offset at a time, image row = tile position
         uint32_t li[RB];
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
         for (int rb = 0; rb < RB; ++rb) li[rb] = (uint32_t)image_slot((wr * RB + rb) * 16 + c16);
         for (int cb = 0; cb < cb_n; ++cb) {
             uint32_t todo = tmask;
-            while (todo) {
+            for (int j = 0; todo != 0u; ++j) {
                 const int k = __builtin_ctz(todo);
                 todo &= todo - 1;
                 __syncthreads();
@@ -451,13 +477,50 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
                     const int32_t r = rows_s[u];
                     return r >= 0 ? nbr[(int64_t)k * m_out + r] : -1;
                 });
-                load_b(S0{}, k, cb);
+                const bool mine = !KS || (j & 3) == wave;
+                if (mine) load_b(S0{}, k, cb);
                 __syncthreads();
-                multiply(S0{}, block_mask(k), li);
+                if (mine) multiply(S0{}, block_mask(k), li);
             }
         }
     }
 
+    if constexpr (KS) {
+        // sum the four waves' partial tiles in a fixed order: half the row blocks at a time through the image's memory
+        // ([wave][row block][column block][lane] float4: no bank conflicts), wave w finishing row block 4 * half + w
+        f32x4* buf = reinterpret_cast<f32x4*>(img);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) buf[((wave * 4 + j) * NBW + n) * 64 + lane] = acc[half * 4 + j][n];
+            __syncthreads();
+            f32x4 sum[NBW];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                sum[n] = buf[((0 * 4 + wave) * NBW + n) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) sum[n] = sum[n] + buf[((w * 4 + wave) * NBW + n) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t orow = rows_s[(half * 4 + wave) * 16 + g * 4 + r];
+                if (orow >= 0) {
+                    float* yr = y + (int64_t)orow * cout + nb0 * 16 + c16;
+                    const float* ar = addend ? addend + (int64_t)orow * cout + nb0 * 16 + c16 : nullptr;
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) {
+                        float v = sum[n][r];
+                        if (ar) v += ar[n * 16];
+                        yr[n * 16] = relu ? (v < 0.0f ? 0.0f : v) : v;
+                    }
+                }
+            }
+        }
+        return;
+    }
     // D layout of v_mfma_f32_16x16x*: row = (lane>>4)*4 + r, col = lane & 15
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -477,14 +540,21 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
         }
 }
 
-template <int WR, int WC, int NBW>
+// timing experiments only (SEG3D_TILE_DBG bit mask, results become WRONG): 1 = image staged for the first slice only,
+// 2 = B fragments never reloaded, 4 = A fragments read from fixed conflict-free slots, 8 = no block skipping
+static const int g_tile_dbg = [] {
+    const char* e = getenv("SEG3D_TILE_DBG");
+    return e ? atoi(e) : 0;
+}();
+
+template <int WR, int WC, int NBW, bool KS = false>
 int launch_tile(const float* x, const int32_t* nbr, const PlanView& pv, int64_t m_out, const void* wp, const float* bias,
                 const float* addend, int cin, int cout, float* y, int relu, hipStream_t st) {
     const int n_tiles = (int)ceil_div64(m_out, kTile);
     const int n_cg = cout / (WC * NBW * 16);
     const unsigned grid = (unsigned)(ceil_div64(n_tiles, 8) * 8 * n_cg);
-    hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles, n_cg,
-                       reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu);
+    hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles, n_cg,
+                       reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu, g_tile_dbg);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -504,19 +574,39 @@ static int tile_layout(int cin, int cout) {
     if (cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15)) return 0;
     if (cout % 192 == 0) return 1;  // 1 x 4 waves of 128 rows x 48 columns
     if (cout % 96 == 0) return 2;   // 2 x 2 waves of 64 rows x 48 columns
+    if (cout == 48) return 6;       // four waves split the chunks of one 128 x 48 tile
+    if (cout == 32) return 7;       // ... 128 x 32
     if (cout % 48 == 0) return 3;   // 4 x 1 waves of 32 rows x 48 columns
     if (cout % 32 == 0) return 4;   // 4 x 1 waves of 32 rows x 32 columns
     return 0;
 }
 
+// SEG3D_TILE_LAYOUT (A/B): force a layout id where it divides cout
+static const int g_tile_layout = [] {
+    const char* e = getenv("SEG3D_TILE_LAYOUT");
+    return e ? atoi(e) : 0;
+}();
+
 int spconv_tile_fwd(const float* x, const int32_t* nbr, const void* plan, int64_t m_out, const void* wp, const float* bias,
                     const float* addend, int cin, int cout, float* y, int relu, hipStream_t st) {
-    const PlanView pv = plan_view(const_cast<void*>(plan), ceil_div64(m_out, kTile));
-    switch (tile_layout(cin, cout)) {
+    const int64_t n_tiles = ceil_div64(m_out, kTile);
+    const PlanView pv = plan_view(const_cast<void*>(plan), n_tiles);
+    int layout = tile_layout(cin, cout);
+    // Few tiles (the 19 k-row level: 153): 192-column workgroups give 1.2 per CU -- a fifth of the CUs runs two, the rest
+    // one and idles -- 128-column workgroups 1.8 per CU at two thirds of the work each.
+    if (layout == 1 && cout % 128 == 0 && n_tiles * (cout / 192) < 400) layout = 5;
+    if (g_tile_layout == 5 && cout % 128 == 0) layout = 5;
+    if (g_tile_layout == 1 && cout % 192 == 0) layout = 1;
+    if (g_tile_layout == 2 && cout % 96 == 0) layout = 2;
+    if (g_tile_layout == 3 && layout >= 6) layout = cout % 48 == 0 ? 3 : 4;  // narrow layers without the chunk split
+    switch (layout) {
         case 1: return launch_tile<1, 4, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
         case 2: return launch_tile<2, 2, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
         case 3: return launch_tile<4, 1, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
         case 4: return launch_tile<4, 1, 2>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
+        case 5: return launch_tile<1, 4, 2>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
+        case 6: return launch_tile<1, 1, 3, true>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
+        case 7: return launch_tile<1, 1, 2, true>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
         default: return SEG3D_EINVAL;
     }
 }

@@ -151,9 +151,16 @@ def test_tiled_conv_is_bit_identical_to_the_per_pair_gather(dev, monkeypatch, ca
             fused = conv.forward_bn_act(t.replace_feature(x), bn, relu=True, res=res).features
         return y.detach().clone(), xin.grad.clone(), fused.clone()
 
-    ref, new = run(False), run(True)
-    for a, b, name in zip(ref, new, ("forward", "input gradient", "conv + bn + residual + relu")):
-        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    ref, new, again = run(False), run(True), run(True)
+    # 48- and 32-column outputs: the four waves of a workgroup split the tile's offsets and sum their partial tiles at the
+    # end -- deterministic, but another summation order than the per-pair kernel's (a few ulp of the largest term)
+    split = {"forward": cout in (32, 48), "input gradient": cin in (32, 48), "conv + bn + residual + relu": cout in (32, 48)}
+    for a, b, c, name in zip(ref, new, again, ("forward", "input gradient", "conv + bn + residual + relu")):
+        assert torch.equal(b, c), name
+        if split[name]:
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), (name, float((a - b).abs().max()))
+        else:
+            assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("cin,cout", [(96, 192), (64, 96), (48, 48), (96, 32)])
@@ -168,12 +175,14 @@ def test_direct_tiles_are_bit_identical_too(dev, cin, cout):
     w = torch.randn(cout, 3, 3, 3, cin, device=dev) / (27 * cin) ** 0.5
     x, bias, res = torch.randn(m, cin, device=dev), torch.randn(cout, device=dev), torch.randn(m, cout, device=dev)
     packed = ops.pack_weight(w, ops.PACK_FWD, use_registry=False)
-    old = ops.conv_act(x, nbr, packed, bias, cin, cout, None, addend=res, relu=True, plan=None)
-    new = ops.conv_act(x, nbr, packed, bias, cin, cout, None, addend=res, relu=True, plan=plan)
-    assert torch.equal(old, new), float((old - new).abs().max())
-    old = ops.conv_act(x, nbr, packed, None, cin, cout, None, addend=None, relu=False, plan=None)
-    new = ops.conv_act(x, nbr, packed, None, cin, cout, None, addend=None, relu=False, plan=plan)
-    assert torch.equal(old, new), float((old - new).abs().max())
+    for kw in (dict(addend=res, relu=True), dict(addend=None, relu=False)):
+        b = bias if kw["relu"] else None
+        old = ops.conv_act(x, nbr, packed, b, cin, cout, None, plan=None, **kw)
+        new = ops.conv_act(x, nbr, packed, b, cin, cout, None, plan=plan, **kw)
+        if cout in (32, 48):  # chunk-split layout: another summation order (see above)
+            assert float((old - new).abs().max()) <= 2e-6 * float(old.abs().max())
+        else:
+            assert torch.equal(old, new), float((old - new).abs().max())
 
 
 def test_tiled_conv_matches_the_fp64_oracle(dev):
