@@ -100,13 +100,14 @@ class _WgradFork:
         """grads: (parameter, gradient launched on the side stream) pairs -- decides whether the wait may be deferred to
         the end of the backward pass (below); gradients that are None are ignored."""
         if self.on and self.used:
-            _drop_stale_deferred()
             if WGRAD_DEFER and _defer_join(self, [(w, gr) for w, gr in grads if gr is not None and w is not None]):
                 return
-            # joining now: this function's sums, and every sum still pending from functions that deferred earlier in the
-            # pass -- what joins here may be ADDED to one of their gradients by the engine (a parameter used twice)
-            jobs = _DEFERRED["jobs"] + self.jobs
-            _DEFERRED["jobs"] = []
+            # joining now: this function's sums, and every sum still pending from functions of THIS pass (graph task) that
+            # deferred earlier -- what joins here may be ADDED to one of their gradients by the engine (a parameter used twice)
+            st = _DEFERRED.get(_state_key(self.device))
+            jobs = (st["jobs"] if st is not None else []) + self.jobs
+            if st is not None:
+                st["jobs"] = []
             if jobs:  # (partial blocks written on the current stream, e.g. LayerNorm's, must be visible to the side stream)
                 self.side.wait_stream(self.main)
                 _run_reduce_jobs(jobs, self.device, self.side)
@@ -141,8 +142,15 @@ class _WgradFork:
 # exception (the engine then skips its final callbacks) leaves state that the first deferral of the NEXT pass drops after
 # joining the streams.  SEG3D_WGRAD_DEFER=0 turns deferral off.
 WGRAD_DEFER = os.environ.get("SEG3D_WGRAD_DEFER", "1") != "0"
-_DEFERRED = {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": [], "task": None, "jobs": []}
+# Pending state per (graph task, device).  A backward pass is one graph task of the engine; a NESTED pass -- the reference
+# trains its encoder layers through reentrant torch.utils.checkpoint (point_transformer_layer.py:321-337), whose backward
+# runs torch.autograd.backward inside a backward function -- is another task with a larger id, has its own final callback,
+# and must not touch the outer pass's pending sums and aliases: it gets its own record.  One record per device: a model
+# split over two GPUs of one process has two side streams and two job tables.
+_DEFERRED = {}
 _DEFER_PROBE = {"done": False, "ok": None}
+_MAX_IDLE_STATES = 4  # records of other graph tasks tolerated beside the current one (see _state_for)
+DEFER_COUNT = 0       # joins deferred so far in this process (tests: a process with a process group must stay at 0)
 
 
 def _graph_task_id():
@@ -150,10 +158,59 @@ def _graph_task_id():
     return fn() if fn is not None else -1
 
 
+def _state_key(device):
+    return (_graph_task_id(), device.index if device.index is not None else torch.cuda.current_device())
+
+
+def _new_state(task, device):
+    return {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": [], "task": task, "jobs": [],
+            "jobs_device": device}
+
+
 def _reset_deferred():
-    st = _DEFERRED
-    st["keep"], st["main"], st["side"], st["seen"], st["twice"], st["fix"], st["task"] = [], None, None, set(), set(), [], None
-    st["jobs"] = []
+    """Forget every pending record (tests; after the probe)."""
+    for key in list(_DEFERRED):
+        _finish_state(key)
+
+
+def _finish_state(key):
+    """What the engine's final callback does for the record `key`: run its pending sums, let the current stream wait for the
+    side stream, repair gradients the engine cloned too early, drop the references."""
+    st = _DEFERRED.pop(key, None)
+    if st is None or st["side"] is None:
+        return
+    if st["jobs"]:  # every pending partial-block sum of the pass in one launch, behind the last producer on either stream
+        st["side"].wait_stream(st["main"])
+        _run_reduce_jobs(st["jobs"], st["jobs_device"], st["side"])
+    st["main"].wait_stream(st["side"])
+    # AccumulateGrad stores the incoming tensor itself when nobody else references it (the normal case: the gradient
+    # buffers below are aliases with their own TensorImpl, made for this check) and CLONES it otherwise -- a clone taken
+    # before the side stream had written the buffer.  Whatever the engine did, .grad holds the finished values from here on.
+    # (A parameter that appeared a second time in the pass was joined on the spot and summed by the engine: its .grad is a
+    # new tensor by right.)
+    for w, alias in st["fix"]:
+        g = w.grad
+        if g is not None and g.data_ptr() != alias.data_ptr() and w.data_ptr() not in st["twice"]:
+            g.copy_(alias.view_as(g))
+
+
+def _state_for(fk):
+    """The record of the current graph task on fk's device, made on first use.  Records of OTHER tasks are left alone
+    while they may be alive: a smaller id is an enclosing pass (or a pass that died in an exception -- the engine then
+    skips its callbacks); a LARGER id can only be a finished-or-dead nested pass (a nested pass ends before its parent
+    runs another function).  Dead records hold references but nothing anybody reads; they are completed (sums run, streams
+    joined -- harmless for a live one too, it only gives up overlap) once more than _MAX_IDLE_STATES pile up."""
+    key = _state_key(fk.device)
+    st = _DEFERRED.get(key)
+    if st is None:
+        task, dev = key
+        for other in [k for k in _DEFERRED if k[1] == dev and k[0] > task]:
+            _finish_state(other)
+        older = sorted(k for k in _DEFERRED if k[1] == dev and k[0] < task)
+        for other in older[: max(0, len(older) - _MAX_IDLE_STATES)]:
+            _finish_state(other)
+        st = _DEFERRED[key] = _new_state(task, fk.device)
+    return key, st
 
 
 _REDUCE_JOB = None
@@ -194,41 +251,10 @@ def _process_group_exists():
     return dist.is_available() and dist.is_initialized()
 
 
-def _final_join():
-    st = _DEFERRED
-    if st["side"] is None:
-        return
-    if st["jobs"]:  # every pending partial-block sum of the pass in one launch, behind the last producer on either stream
-        st["side"].wait_stream(st["main"])
-        _run_reduce_jobs(st["jobs"], st["jobs_device"], st["side"])
-    st["main"].wait_stream(st["side"])
-    # AccumulateGrad stores the incoming tensor itself when nobody else references it (the normal case: the gradient
-    # buffers below are aliases with their own TensorImpl, made for this check) and CLONES it otherwise -- a clone taken
-    # before the side stream had written the buffer.  Whatever the engine did, .grad holds the finished values from here on.
-    # (A parameter that appeared a second time in the pass was joined on the spot and summed by the engine: its .grad is a
-    # new tensor by right.)
-    for w, alias in st["fix"]:
-        g = w.grad
-        if g is not None and g.data_ptr() != alias.data_ptr() and w.data_ptr() not in st["twice"]:
-            g.copy_(alias.view_as(g))
-    _reset_deferred()
-
-
-def _drop_stale_deferred():
-    """State left behind by a pass that raised before the engine ran its callbacks (another graph task's): whatever it
-    launched is joined now and its aliases are dropped -- they belong to gradients nobody will read."""
-    st = _DEFERRED
-    if st["side"] is not None and st["task"] != _graph_task_id():
-        st["main"].wait_stream(st["side"])
-        _reset_deferred()
-
-
 def _defer_join(fk, grads):
-    st = _DEFERRED
-    _drop_stale_deferred()
     if torch.is_grad_enabled() or not grads or _DEFER_PROBE["ok"] is False or _process_group_exists():
         return False
-    task = _graph_task_id()
+    key, st = _state_for(fk)
     bases = [w if w._base is None else w._base for w, _ in grads]
     if any(base.data_ptr() in st["seen"] for base in bases):
         st["twice"].update(base.data_ptr() for base in bases)  # second use: this call joins now, the engine sums
@@ -237,20 +263,24 @@ def _defer_join(fk, grads):
         if (not base.is_leaf or base.grad is not None or base._backward_hooks or not base.is_contiguous()
                 or getattr(base, "_post_accumulate_grad_hooks", None)):
             return False
-    try:
-        torch.autograd.Variable._execution_engine.queue_callback(_final_join)
-    except RuntimeError:  # not inside a backward pass of the engine (a direct call): join now
-        return False
+    if st["side"] is None:  # first deferral of this graph task: its final callback completes the record
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda key=key: _finish_state(key))
+        except RuntimeError:  # not inside a backward pass of the engine (a direct call): join now
+            if not st["jobs"]:
+                _DEFERRED.pop(key, None)
+            return False
     for base, (w, gr) in zip(bases, grads):
         st["seen"].add(base.data_ptr())
         if w is base:
             st["fix"].append((base, gr.detach()))
         else:
             st["keep"].append(gr.detach())  # gradient of a view of the parameter: autograd scatters it, no .grad to check
-    st["main"], st["side"], st["task"] = fk.main, fk.side, task
+    global DEFER_COUNT
+    DEFER_COUNT += 1
+    st["main"], st["side"] = fk.main, fk.side
     st["keep"].append(fk.keep)
     st["jobs"].extend(fk.jobs)
-    st["jobs_device"] = fk.device
     fk.keep = []
     fk.jobs = []
     return True

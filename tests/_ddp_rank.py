@@ -42,7 +42,7 @@ def main():
     probe = model.point_transformer.swformer_block3[1].layers[0].mlp.fc1.weight.grad
     out = {"rank": rank, "world": world, "backend": dist.get_backend(), "total": float(sum(fp.values())),
            "n_nonfinite": int(sum(1 for v in fp.values() if v != v)), "probe": probe.double().flatten()[:64].tolist(),
-           "deferred_in_this_process": bool(ops._DEFERRED["seen"]) or bool(ops._DEFERRED["fix"])}
+           "deferred_in_this_process": bool(ops._DEFERRED) or ops.DEFER_COUNT > 0}
     sys.stdout.write("\nDDPRANK " + json.dumps(out) + "\n")  # one write: the ranks share the pipe
     sys.stdout.flush()
     dist.barrier()

@@ -83,3 +83,65 @@ def test_inference_conv_blocks_fold_batchnorm_into_one_launch():
         # new statistics must invalidate the folded packs
         sd = {k: (v * 1.3 + 0.1 if v.is_floating_point() else v) for k, v in net.state_dict().items()}
         net.load_state_dict(sd)
+
+
+def test_reentrant_checkpoint_gives_the_same_gradients():
+    """The reference trains every SWFormerBlock layer under torch.utils.checkpoint (point_transformer_layer.py:321-337,
+    reentrant: the recompute and its backward run as a NESTED autograd pass inside the outer backward).  With the weight
+    gradients on the side stream and their joins deferred to the end of a pass, the nested pass must complete its own
+    gradients without disturbing the pending ones of the enclosing pass: an encoder layer and a conv block, each between
+    two plain Linear layers whose gradients are pending while the nested pass runs, give bit-identical gradients with and
+    without the checkpoint."""
+    from torch.utils.checkpoint import checkpoint
+    from openseg3d_amd import ops, scene, segformer, spconv, swformer
+    assert ops.WGRAD_STREAM and ops.WGRAD_DEFER
+    dev = torch.device("cuda:0")
+    ops.probe_deferred_join(dev)
+    torch.manual_seed(3)
+    c = 96
+    part = swformer.SparseWindowPartitionLayer({0: {"max_tokens": 800, "batching_range": [0, 100000]}}, [10, 10, 8],
+                                               [360.0, 360.0, 16.0])
+    pts = scene.make_small_scene(5, 9000, extent=12.0)
+    coords = np.unique(np.floor((pts[:, :3] - pts[:, :3].min(0)) / 0.4).astype(np.int32)[:, ::-1], axis=0)
+    coords = torch.from_numpy(np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords], 1)).to(dev)
+    shape = [int(v) + 2 for v in coords[:, 1:].max(0)[0].tolist()]
+    plan = part.plan(coords, 1, c)
+    layer = swformer.EncoderLayer(c, 8, 2 * c, drop_path_rate=0.2).to(dev).train()
+    norm_fn = lambda ch: torch.nn.BatchNorm1d(ch, eps=1e-3, momentum=0.01)  # noqa: E731
+    block = segformer.SparseBasicBlock(c, c, norm_fn, torch.nn.ReLU(inplace=True), indice_key="subm1").to(dev).train()
+    head, tail = segformer.RowLinear(c, c).to(dev), segformer.RowLinear(c, c).to(dev)
+    level = spconv.SiteLevel(coords, shape, 1)
+    params = [p for m in (head, layer, block, tail) for p in m.parameters()]
+    x0 = torch.randn(coords.shape[0], c, device=dev)
+    gout = torch.randn_like(x0)
+
+    def conv_part(feats):
+        return block(spconv.SparseConvTensor(feats, coords, shape, 1, _level=level)).features
+
+    def run(ckpt):
+        for p in params:
+            p.grad = None
+        for m in block.modules():  # same running statistics at the start of both runs
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        torch.manual_seed(11)
+        x = x0.clone().requires_grad_(True)
+        h = head(x)
+        if ckpt:
+            h = checkpoint(layer, h, plan.pos[0], plan.index[0], use_reentrant=True)
+            h = checkpoint(conv_part, h, use_reentrant=True)
+        else:
+            h = conv_part(layer(h, plan.pos[0], plan.index[0]))
+        y = tail(h)
+        y.backward(gout)
+        torch.cuda.synchronize()
+        assert not ops._DEFERRED  # every pass, nested ones included, completed its record
+        return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]
+
+    before = ops.DEFER_COUNT
+    ya, dxa, ga = run(False)
+    assert ops.DEFER_COUNT > before  # the joins really were deferred
+    yb, dxb, gb = run(True)
+    assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
+    for a, b, p in zip(ga, gb, params):
+        assert torch.equal(a, b), tuple(p.shape)

@@ -460,13 +460,16 @@ def test_deferred_join_probe_passes_and_catches_a_broken_engine(monkeypatch):
     monkeypatch.setitem(ops._DEFER_PROBE, "done", False)
     monkeypatch.setitem(ops._DEFER_PROBE, "ok", None)
     engine = torch.autograd.Variable._execution_engine
-    monkeypatch.setattr(ops, "_final_join", lambda: None)  # the callback runs but no longer joins the streams
+    finish = ops._finish_state
+    monkeypatch.setattr(ops, "_finish_state", lambda key: None)  # the callback runs but no longer joins the streams
     with pytest.warns(UserWarning, match="deferred weight-gradient join"):
         assert ops.probe_deferred_join(dev) is False
     assert ops.WGRAD_DEFER is False
     del engine
     torch.cuda.synchronize()
+    monkeypatch.setattr(ops, "_finish_state", finish)
     ops._reset_deferred()
+    assert not ops._DEFERRED
 
 
 def _ddp_ranks(world, backend, env=None):

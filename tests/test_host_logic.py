@@ -227,6 +227,7 @@ def test_deferred_join_bookkeeping_is_safe_by_construction(monkeypatch):
             self.waits += 1
 
     log = []
+    ctx_jobs = []  # pending partial-block sums a backward function hands over with its deferral
 
     class Fn(torch.autograd.Function):
         @staticmethod
@@ -237,7 +238,7 @@ def test_deferred_join_bookkeeping_is_safe_by_construction(monkeypatch):
         @staticmethod
         def backward(ctx, dy):
             gr = torch.full_like(ctx.w, 2.0)
-            fk = SimpleNamespace(main=FakeStream(), side=FakeStream(), keep=[gr], jobs=[], device=None)
+            fk = SimpleNamespace(main=FakeStream(), side=FakeStream(), keep=[gr], jobs=list(ctx_jobs), device=SimpleNamespace(index=0))
             log.append((ops._defer_join(fk, [(ctx.w, gr)]), fk))
             return dy * ctx.w.sum(), gr
 
@@ -256,14 +257,14 @@ def test_deferred_join_bookkeeping_is_safe_by_construction(monkeypatch):
     w = torch.ones(4, requires_grad=True)
     Fn.apply(x, w).sum().backward()
     deferred, fk = log.pop()
-    assert deferred and fk.main.waits == 1 and ops._DEFERRED["side"] is None and not ops._DEFERRED["seen"]
+    assert deferred and fk.main.waits == 1 and not ops._DEFERRED
     assert torch.equal(w.grad, torch.full((4,), 2.0))
 
     # a process group exists -> joined at the end of the backward function, whoever wrapped the model
     monkeypatch.setattr(ops, "_process_group_exists", lambda: True)
     w.grad = None
     Fn.apply(x, w).sum().backward()
-    assert log.pop()[0] is False and ops._DEFERRED["side"] is None
+    assert log.pop()[0] is False and not ops._DEFERRED
     monkeypatch.setattr(ops, "_process_group_exists", lambda: False)
 
     # the probe said no -> never deferred
@@ -273,15 +274,58 @@ def test_deferred_join_bookkeeping_is_safe_by_construction(monkeypatch):
     assert log.pop()[0] is False
     monkeypatch.setitem(ops._DEFER_PROBE, "ok", True)
 
-    # a pass that dies after a deferral leaves state; the next pass joins and drops it before deferring again
+    # a pass that dies after a deferral leaves its record behind (the engine skips the callbacks): the next pass has its
+    # own record and is not disturbed; dead records are completed once more than _MAX_IDLE_STATES pile up, or on reset
     w.grad = None
     with pytest.raises(RuntimeError, match="boom"):
         Fn.apply(Boom.apply(x), w).sum().backward()
     deferred, dead = log.pop()
-    assert deferred and ops._DEFERRED["side"] is dead.side and dead.main.waits == 0  # callback skipped
+    assert deferred and len(ops._DEFERRED) == 1 and dead.main.waits == 0  # callback skipped
     w2 = torch.ones(4, requires_grad=True)
     Fn.apply(x, w2).sum().backward()
     deferred, fk = log.pop()
-    assert deferred and dead.main.waits == 1 and fk.main.waits == 1
-    assert ops._DEFERRED["side"] is None and not ops._DEFERRED["fix"] and not ops._DEFERRED["keep"]
+    assert deferred and fk.main.waits == 1 and len(ops._DEFERRED) == 1
     assert torch.equal(w2.grad, torch.full((4,), 2.0))
+    for _ in range(ops._MAX_IDLE_STATES + 2):
+        wd = torch.ones(4, requires_grad=True)
+        with pytest.raises(RuntimeError, match="boom"):
+            Fn.apply(Boom.apply(x), wd).sum().backward()
+        log.pop()
+    assert len(ops._DEFERRED) <= ops._MAX_IDLE_STATES + 1 and dead.main.waits == 1  # the oldest were completed
+    ops._reset_deferred()
+    assert not ops._DEFERRED
+
+    # a NESTED pass (reentrant torch.utils.checkpoint runs torch.autograd.backward inside a backward function,
+    # point_transformer_layer.py:321-337) is another graph task: it completes its own record at its own end and leaves the
+    # enclosing pass's pending sums and aliases alone
+    ran = []
+    monkeypatch.setattr(ops, "_run_reduce_jobs", lambda jobs, device, stream: ran.append(list(jobs)))
+
+    class Nest(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w, ctx.x = w, x.detach()
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, dy):
+            assert len(ops._DEFERRED) == 1  # the outer pass's record, made by the Fn that ran before us
+            outer = next(iter(ops._DEFERRED.values()))
+            assert outer["jobs"] == ["outer sum"]
+            with torch.enable_grad():
+                xi = ctx.x.clone().requires_grad_()
+                inner = Fn.apply(xi, ctx.w).sum()
+            ctx_jobs[:] = ["inner sum"]
+            torch.autograd.backward(inner)
+            ctx_jobs[:] = []
+            deferred_inner, fki = log.pop()
+            assert deferred_inner and fki.main.waits == 1 and ran == [["inner sum"]]  # the nested task finished its own record
+            assert len(ops._DEFERRED) == 1 and outer["jobs"] == ["outer sum"] and len(outer["fix"]) == 1
+            return dy, None
+
+    w_out, w_in = torch.ones(4, requires_grad=True), torch.ones(4, requires_grad=True)
+    ctx_jobs[:] = ["outer sum"]
+    Fn.apply(Nest.apply(x, w_in), w_out).sum().backward()
+    deferred, fk = log.pop()
+    assert deferred and fk.main.waits == 1 and ran == [["inner sum"], ["outer sum"]] and not ops._DEFERRED
+    assert torch.equal(w_out.grad, torch.full((4,), 2.0)) and torch.equal(w_in.grad, torch.full((4,), 2.0))
