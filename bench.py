@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
 MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md:43
-PMC_TRAFFIC_FILES = ("r03_pmc_conv_traffic.json", "r03_pmc_conv_traffic_dense2m.json", "r03_pmc_conv_traffic_cylinder.json",
+PMC_TRAFFIC_FILES = ("r04_pmc_conv_traffic.json", "r04_pmc_conv_traffic_dense2m.json", "r04_pmc_conv_traffic_cylinder.json",
+                     "r04_pmc_conv_traffic_multi_sweeps.json", "r04_pmc_conv_traffic_spnet.json", "r03_pmc_conv_traffic.json", "r03_pmc_conv_traffic_dense2m.json", "r03_pmc_conv_traffic_cylinder.json",
                      "r03_pmc_conv_traffic_multi_sweeps.json", "r03_pmc_conv_traffic_spnet.json", "r02_pmc_conv_traffic.json")
 ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
 
@@ -45,6 +46,17 @@ WORKLOADS = {
     "dense2m": "synthetic dense scene, 2 M points @0.02 m voxels in a 28.8 m x 28.8 m x 1.28 m block "
                "(BASELINE configs[4] / SURVEY 8d Config 5)",
 }
+
+
+def lib_sha16():
+    """First 16 hex digits of the sha256 of the loaded libseg3d_hip.so: ties a committed PMC file to the build it measured."""
+    import hashlib
+    from openseg3d_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -71,6 +83,8 @@ def parse():
                          "carries its agreement with the fp32-storage forward of the same weights.  The training step is unchanged.")
     ap.add_argument("--sync-bn", action="store_true", help="tools/train.py --sync_bn: SyncBatchNorm over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-exact", action="store_true",
+                    help="skip the child run that times the same step with exact-fp32 products (SEG3D_CONV_PRECISION=fp32)")
     ap.add_argument("--no-pipeline", action="store_true", help="build each step's batch and index plan at the start of the step "
                     "instead of on the pipeline stream during the previous step")
     ap.add_argument("--cpu-points", type=int, default=-1,
@@ -186,7 +200,7 @@ def conv_roofline(model, batch, dev):
     # HBM traffic per launch QUOTED from the committed PMC passes of this workload (FETCH_SIZE doubled per the gfx950
     # correction + WRITE_SIZE, two separate rocprofv3 --pmc runs; counters cannot be read inside this process); only
     # quoted when the profiled workload is the one just run (same algorithmic bytes), otherwise null.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_lib = None, None, None
     for name in PMC_TRAFFIC_FILES:
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
@@ -195,15 +209,21 @@ def conv_roofline(model, batch, dev):
             p = json.load(f)
         if abs(p.get("algorithmic_bytes_per_launch", 0) - tot_bytes / n) <= 0.01 * tot_bytes / n:
             traffic, traffic_src = p["traffic_bytes_per_launch"], f"quoted from profiles/{name} (rocprofv3 --pmc, same workload)"
+            traffic_lib = p.get("lib_sha16")
             break
+    # the counters were read from ONE build of the library: say so when the library that just ran is another one
+    here = lib_sha16()
+    traffic_stale = None if traffic is None else bool(traffic_lib != here)
     # `frac` follows SURVEY 8(d)'s formula, which counts a row once per offset that gathers it -- a gather RATE, most of which
     # is served by L1 / L2.  What must cross the HBM interface at least once is the footprint (every input and output row
     # once + weights + table): that second fraction is the one to read as HBM utilisation.
     foot_frac = foot_bytes / tot_ms / 1e6 / HBM_PEAK_GBS if tot_ms > 0 else 0.0
-    return {"bound": "hbm", "kernel": f"spconv_split_kernel (all {n_layers} sparse-conv launches of one forward, per-layer median of {passes} forwards)",
+    return {"bound": "hbm", "kernel": f"spconv_tile_kernel / spconv_split_kernel (all {n_layers} sparse-conv launches of one forward, per-layer median of {passes} forwards)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_hbm_by_footprint": round(foot_frac, 4),
+            "frac_by_counters": None if traffic is None else round(traffic * n / tot_ms / 1e6 / HBM_PEAK_GBS, 4),
             "footprint_bytes_per_launch": int(foot_bytes / n), "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_lib_sha16": traffic_lib, "lib_sha16": here, "traffic_stale": traffic_stale,
             "launches": n_layers, "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
 
 
@@ -331,6 +351,7 @@ def main():
 
     # logit parity + CPU baseline on the weights the run starts from (seed 0), before anything is timed
     baseline = None
+    parity_sample = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded samples (10-30 s of CPU work): the dense scene's first 150 k points; of a multi-sweep scene the first
         # 30 k current-sweep rows with their image features and twice as many history rows (the oracle's DeepFusion kNN is
@@ -350,6 +371,20 @@ def main():
         model.eval()
         report, o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
         baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids))
+        parity_sample = (sample, s_cur, s_img)
+        if cyl:
+            # how many points land in ANOTHER voxel when phi comes from numpy's float32 arctan2 (what the reference's loader
+            # computes, pointops_utils.py:8-11) instead of the device's correctly rounded value (<= 4 ulp apart)
+            from oracle import index_ops
+            host_rows = scene.cart2polar_rows(scenes_np[0][: sample.shape[0]])
+            ch, ih = index_ops.voxelize(host_rows, ds.voxel_size, ds.point_cloud_range)
+            cd, idv = index_ops.voxelize(sample, ds.voxel_size, ds.point_cloud_range)
+            # voxel numbering is first-seen order on both sides: compare the CELLS (-1 = out of range)
+            cell_h = np.where(ih[:, None] >= 0, ch[np.maximum(ih, 0)], -1)
+            cell_d = np.where(idv[:, None] >= 0, cd[np.maximum(idv, 0)], -1)
+            moved = int((cell_h != cell_d).any(1).sum())
+            baseline[1]["cylinder_phi"] = {"points_in_another_voxel_under_numpy_phi": moved, "n_points": int(sample.shape[0]),
+                                           "frac": moved / max(int(sample.shape[0]), 1), "bar": 1e-4}
         del o_res
 
     hi = None
@@ -598,6 +633,22 @@ def main():
         taus = [float(p.detach()) for n, p in model.named_parameters() if n.endswith(".tau")]
         if taus and out["attention_roofline"] is not None:
             out["attention_roofline"]["tau_range_after_steps"] = [round(min(taus), 4), round(max(taus), 4)]
+        if (train and world == 1 and not args.no_fp32_exact and _ops.CONV_PRECISION == "bf16x3" and args.workload == "one_sweep"
+                and args.segmentor == "segformer"):
+            # the same step with every conv / Linear product an exact fp32 MFMA (the reference's arithmetic), in a fresh child
+            # process (the switch is read at import): the same-precision number, driver-recorded
+            import subprocess
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--scenes", "2",
+                                    "--no-cpu-baseline", "--no-fp32-exact"], capture_output=True, text=True, timeout=600,
+                                   env=dict(os.environ, SEG3D_CONV_PRECISION="fp32"))
+            fp32 = {"error": child.stderr[-300:]}
+            for line in child.stdout.splitlines():
+                if line.startswith("{"):
+                    d = json.loads(line)
+                    fp32 = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "dtype": d["dtype"],
+                            "fwd_only_ms_per_step": d["fwd_only"]["ms_per_step"], "steps": d["steps"],
+                            "note": "SEG3D_CONV_PRECISION=fp32: v_mfma_f32_16x16x4_f32 products (1/16 of the bf16 MFMA rate)"}
+            out["fp32_exact"] = fp32
         if baseline is not None:
             out["cpu_baseline"], out["parity"] = baseline
             # the trained module against a fresh module loaded from its state_dict: every cached operand (packed weights,
@@ -608,6 +659,12 @@ def main():
                 a = model(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0], cyl))
                 c = fresh(B.batch_from_resident(resident[0], offsets[0], ds.voxel_size, ds.point_cloud_range, images[0], cyl))
             out["parity"]["trained_vs_reloaded_max_abs_diff"] = float((a["point_out"] - c["point_out"]).abs().max())
+            if train and parity_sample is not None:
+                # the same comparison on the weights the run ENDS with (a second oracle forward on the host cores)
+                _, o_res, o_coords, o_ids = cpu_baseline(*parity_sample, cfg, ds, model)
+                after = parity_report(*parity_sample, ds, model, dev, o_res, o_coords, o_ids)
+                out["parity"]["after_training"] = {k: after[k] for k in after if k.startswith("max_") or k.endswith("bit_exact")}
+                out["parity"]["after_training"]["steps"] = args.steps + args.warmup
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
             json.dump(per_layer, f, indent=1)

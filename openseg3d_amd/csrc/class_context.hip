@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256) void ctx_bwd_probs(const float* __restrict__ w
     dprobs[i] = scale * (wg[i] - w[i] * delta);
 }
 
-bool bad_shape(int K, int C) { return K < 1 || K > kMaxK || C < 4 || (C & 3) || C > 1024; }
+// classes x channels is capped by the backward's dynamic LDS block (classes * C + 128 rows * 32 classes floats) at the
+// 64 KiB a kernel gets without opting in to more: the validated range (SPNet: 22 x 128 = 27 KiB)
+bool bad_shape(int K, int C) {
+    return K < 1 || K > kMaxK || C < 4 || (C & 3) || C > 1024 || ((size_t)K * C + (size_t)kChunk * kMaxK) * sizeof(float) > 64 * 1024;
+}
 
 }  // namespace
 
@@ -199,7 +203,6 @@ int seg3d_class_context_bwd(const float* feats, const float* weights, const floa
     float* wg = scratch;
     float* colsum = scratch + m * classes;
     const size_t smem = ((size_t)classes * c + (size_t)kChunk * kMaxK) * sizeof(float);
-    if (smem > 160 * 1024) return SEG3D_EINVAL;
     hipLaunchKernelGGL(ctx_bwd_rows, dim3((unsigned)n_chunks), dim3(256), smem, st, feats, weights, dcontext, offsets,
                        reinterpret_cast<const int2*>(chunks), classes, c, dfeats, wg, colsum);
     SEG3D_CHECK_LAUNCH();

@@ -1403,12 +1403,11 @@ class _WindowAttnFn(torch.autograd.Function):
         dev = v.device
         out = torch.empty((m, c), dtype=torch.float32, device=dev)
         lse = torch.empty((m, heads), dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, dh), dev)
         tau_f = tau.reshape(-1)
         _lib.call("seg3d_window_attn_fwd", _ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0),
                   _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0), _ptr(wi.tile_item),
                   int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m, int(wi.n_windows), heads, dh,
-                  _ptr(tau_f), float(tau_min), 0.0, 0, _ptr(out), _ptr(lse), _ptr(ws), ws.numel(), _stream())
+                  _ptr(tau_f), float(tau_min), 0.0, 0, _ptr(out), _ptr(lse), None, 0, _stream())  # (the forward needs no workspace)
         ctx.save_for_backward(q, k, v, tau, out, lse)
         ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
         return out
@@ -1443,14 +1442,13 @@ class _WindowAttnPackedFn(torch.autograd.Function):
         dev = v.device
         out = torch.empty((m, c), dtype=torch.float32, device=dev)
         lse = torch.empty((m, heads), dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("seg3d_window_attn_workspace_bytes", m, int(wi.n_tiles), heads, dh), dev)
         ctx.drop_p, ctx.drop_seed = drop_p, drop_seed
         kp = ctypes.c_void_p(qk.data_ptr() + 4 * c)
         _lib.call("seg3d_window_attn_fwd", _ptr(qk), kp, _ptr(v), 2 * c, 2 * c, c,
                   _ptr(wi.tok), _ptr(wi.win_start), _ptr(wi.win_count), _ptr(wi.win_tile0), _ptr(wi.tile_item),
                   int(wi.n_tiles), _ptr(wi.qg_item), int(wi.n_qgroups), m, int(wi.n_windows), heads, dh,
-                  _ptr(tau.reshape(-1)), float(tau_min), float(drop_p), int(drop_seed), _ptr(out), _ptr(lse), _ptr(ws),
-                  ws.numel(), _stream())
+                  _ptr(tau.reshape(-1)), float(tau_min), float(drop_p), int(drop_seed), _ptr(out), _ptr(lse), None, 0,
+                  _stream())  # (no workspace: seg3d_window_attn_workspace_bytes sizes the backward's)
         ctx.save_for_backward(qk, v, tau, out, lse)
         ctx.wi, ctx.heads, ctx.tau_min = wi, heads, tau_min
         return out
@@ -1976,13 +1974,18 @@ def class_context_plan(row_offsets, device):
     return plan
 
 
+def class_context_fits(classes, channels):
+    """Shapes the fused kernels take: the backward keeps d context [classes, C] + a 128 x 32 tile in 64 KiB of LDS."""
+    return 1 <= classes <= 32 and channels % 4 == 0 and 4 <= channels <= 1024 and (classes * channels + 128 * 32) * 4 <= 64 * 1024
+
+
 def class_context(feats, probs, row_offsets, scale=1.0):
     """context [B, classes, C] = per sample (rows offsets[b-1] .. offsets[b]) softmax over the sample's rows of
     scale * probs[:, k], times feats (SpatialGatherModule, seg3d/models/layers/ocr.py:10-36), any batch size in one
     launch sequence, differentiable w.r.t. feats and probs.  row_offsets: cumulative row counts per sample (python ints)."""
     _need_gpu(feats, probs)
-    if probs.shape[1] > 32 or feats.shape[1] % 4 or feats.shape[1] > 1024:
-        raise _lib.Seg3dError("class_context: at most 32 classes, channels a multiple of 4 and <= 1024")
+    if not class_context_fits(probs.shape[1], feats.shape[1]):
+        raise _lib.Seg3dError("class_context: at most 32 classes, channels a multiple of 4, classes * channels <= 12288")
     return _ClassContextFn.apply(feats, probs, class_context_plan(row_offsets, feats.device), float(scale))
 
 

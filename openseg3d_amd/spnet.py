@@ -59,7 +59,7 @@ class SpatialGatherModule(nn.Module):
         self.scale = scale
 
     def forward(self, feats, probs, batch_size, batch_indices, offsets=None):
-        if offsets is not None and feats.is_cuda and probs.shape[1] <= 32 and feats.shape[1] % 4 == 0 and feats.shape[1] <= 1024:
+        if offsets is not None and feats.is_cuda and ops.class_context_fits(probs.shape[1], feats.shape[1]):
             # samples are row spans: one segmented softmax-matmul for the whole batch (seg3d_class_context_fwd / _bwd)
             return ops.class_context(feats, probs, offsets[:batch_size], self.scale)
         out = []

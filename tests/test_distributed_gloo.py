@@ -19,30 +19,15 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    from openseg3d_amd import config, dist as D, segformer
-    r, w, _ = D.init_from_env(backend="gloo")
-    assert (r, w) == (rank, world)
+    from openseg3d_amd import dist as D
+    r, w, _ = D.init_job(backend="gloo")
+    assert (r, w) == (rank, world) and dist.is_initialized()
     # scenes shard without overlap
     seeds = D.scene_seeds(rank, 3)
     gathered = [None] * world
     dist.all_gather_object(gathered, seeds)
     assert sorted(sum(gathered, [])) == list(range(3 * world))
-    assert D.shard_indices(5, rank, world) == ([0, 2, 4] if rank == 0 else [1, 3, 0])
-    # every rank starts from rank 0's weights
-    torch.manual_seed(100 + rank)
-    cfg = config.default_cfg()
-    model = segformer.build_segmentor(cfg, config.DatasetSpec(cfg))
-    D.broadcast_parameters(model)
-    probe = getattr(model.point_transformer.conv_down2, "0").weight.detach().clone()
-    ref = probe.clone()
-    dist.broadcast(ref, src=0)
-    assert torch.equal(probe, ref)
-    # gradient exchange: mean over ranks, bucket boundaries included
-    for i, p in enumerate(model.parameters()):
-        p.grad = torch.full_like(p, float(rank + 1) * (1 + i % 3))
-    D.allreduce_gradients(model, bucket_bytes=1 << 20)
-    for i, p in enumerate(model.parameters()):
-        assert torch.allclose(p.grad, torch.full_like(p, 1.5 * (1 + i % 3)))
+    from openseg3d_amd import config, segformer  # noqa: F401  (the package imports on a CPU-only rank)
     # the wrapper bench.py trains through (tools/train.py:246-247, 276-279): DistributedDataParallel over this process group;
     # after backward every rank holds the mean of the ranks' gradients
     torch.manual_seed(7)

@@ -15,8 +15,8 @@ def conv_dispatches(path, counter):
     per = {}
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        # sparse instantiations: spconv_split_kernel<NBT, RB, DENSE = false, IO>
-        if not re.search(r"spconv_split_kernel<\d+, \d+, false", n) or r["Counter_Name"] != counter:
+        # sparse instantiations: spconv_split_kernel<NBT, RB, DENSE = false, IO> and every spconv_tile_kernel
+        if not re.search(r"spconv_split_kernel<\d+, \d+, false|spconv_tile_kernel<", n) or r["Counter_Name"] != counter:
             continue
         d = int(r["Dispatch_Id"])
         per[d] = (n, per.get(d, (n, 0.0))[1] + float(r["Counter_Value"]))
@@ -25,6 +25,9 @@ def conv_dispatches(path, counter):
 
 def main():
     fetch_csv, write_csv, layers_json, out = sys.argv[1:5]
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     layers = json.load(open(layers_json))
     n = len(layers)
     f = conv_dispatches(fetch_csv, "FETCH_SIZE")[-n:]
@@ -44,7 +47,8 @@ def main():
                       "bench.py --mode fwd --steps 2 --warmup 1 --no-cpu-baseline; tools/pmc_conv_traffic.py",
            "correction": "gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> doubled (MI355X_MICROARCH.md section "
                          "HBM); WRITE_SIZE taken as is; counter unit KiB",
-           "kernel": f"spconv_split_kernel<*, 2, false> ({n} sparse-conv launches of the scene-0 forward)",
+           "kernel": f"spconv_tile_kernel<*> / spconv_split_kernel<*, 2, false> ({n} sparse-conv launches of the scene-0 forward)",
+           "lib_sha16": bench.lib_sha16(),
            "traffic_bytes_per_launch": int(tot_t / n), "algorithmic_bytes_per_launch": int(tot_a / n), "layers": rows}
     json.dump(doc, open(out, "w"), indent=1)
     print(f"traffic {tot_t / n / 1e6:.1f} MB per launch, algorithmic {tot_a / n / 1e6:.1f} MB per launch")
