@@ -113,7 +113,7 @@ def test_bench_prints_one_contract_line():
         assert r["traffic_stale"] == (r["traffic_lib_sha16"] != r["lib_sha16"])
     f = d["fp32_exact"]
     assert f["ms_per_step"] > 0 and f["value"] > 0 and f["dtype"] == "f32" and f["steps"] == 5
-    assert f["fwd_only_ms_per_step"] > d["fwd_only"]["ms_per_step"]  # exact-fp32 products run at 1/16 of the bf16 MFMA rate
+    assert f["fwd_only_ms_per_step"] > 20.0  # exact-fp32 products run at 1/16 of the bf16 MFMA rate (default path: ~13 ms)
     assert len(d["conv_layers"]) == 20 and {l["bound"] for l in d["conv_layers"]} == {"hbm", "mfma_bf16x3"}
     assert d["fwd_only"]["value"] > d["value"]
 
