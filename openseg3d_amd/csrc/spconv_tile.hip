@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void plan_kernel(const uint32_t* __restri
 // gather kernel, whose rows accumulate offset by offset).
 template <int WR, int WC, int NBW, bool KS = false>
 __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
-                                                                  PlanView pv, int64_t m_out, int n_tiles, int n_cg,
+                                                                  PlanView pv, int64_t m_out, int n_tiles, int n_cg, int run,
                                                                   const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                                   const float* __restrict__ addend, int cin, int cout,
                                                                   float* __restrict__ y, int relu, int dbg) {
@@ -260,9 +260,12 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int wr = KS ? 0 : wave / WC, wc = KS ? 0 : wave % WC;
-    // workgroups of one tile (its column groups) sit on one XCD (blockIdx % 8), side by side in launch order
-    const int grp = blockIdx.x / (8 * n_cg), rem = blockIdx.x % (8 * n_cg);
-    const int cg = rem >> 3, tile = grp * 8 + (rem & 7);
+    // Workgroup -> (tile, column group): blockIdx % 8 is the XCD (its own L2).  An XCD walks RUNS of `run` consecutive
+    // tiles, column groups of a tile side by side: consecutive tiles are spatial neighbours (Morton order) whose halo rows
+    // overlap, so what one stages the next finds in the same L2 instead of pulling it over the fabric again.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int cg = seq % n_cg, tl = seq / n_cg;
+    const int tile = (tl / run) * (8 * run) + xcd * run + (tl % run);
     if (tile >= n_tiles) return;
     const int cb_n = (cin + 31) >> 5, nb_n = cout >> 4;
     const int nb0 = (cg * WC + wc) * NBW;
@@ -547,13 +550,22 @@ static const int g_tile_dbg = [] {
     return e ? atoi(e) : 0;
 }();
 
+// SEG3D_TILE_RUN (A/B): consecutive tiles per XCD run (0 = automatic)
+static const int g_tile_run = [] {
+    const char* e = getenv("SEG3D_TILE_RUN");
+    return e ? atoi(e) : 0;
+}();
+
 template <int WR, int WC, int NBW, bool KS = false>
 int launch_tile(const float* x, const int32_t* nbr, const PlanView& pv, int64_t m_out, const void* wp, const float* bias,
                 const float* addend, int cin, int cout, float* y, int relu, hipStream_t st) {
     const int n_tiles = (int)ceil_div64(m_out, kTile);
     const int n_cg = cout / (WC * NBW * 16);
-    const unsigned grid = (unsigned)(ceil_div64(n_tiles, 8) * 8 * n_cg);
-    hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles, n_cg,
+    int run = n_tiles / 64;  // ~8 runs per XCD: the tail imbalance stays below an eighth
+    run = run < 1 ? 1 : (run > 16 ? 16 : run);
+    if (g_tile_run > 0) run = g_tile_run;
+    const unsigned grid = (unsigned)(ceil_div64(n_tiles, 8 * run) * 8 * run * n_cg);
+    hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles, n_cg, run,
                        reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu, g_tile_dbg);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
