@@ -222,6 +222,14 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
                        int64_t m_in, int32_t cin, int32_t cout, int32_t flags /* bit2: split-bf16 */,
                        float* dw, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The first half of seg3d_spconv_wgrad alone (split-bf16 arithmetic): partial blocks part[chunks][27 * cin * cout] stay in the
+ * workspace, *chunks (host) = their count (0 for m_out == 0: the sum then writes zeros); the fixed-order sum is queued by the
+ * caller with the other parameter-gradient sums of the backward pass (seg3d_reduce_partials_batched).  spconv has no
+ * counterpart: it accumulates weight gradients with atomics inside its own kernels (call sites spconv_utils.py:13-32). */
+int seg3d_spconv_wgrad_partials(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int64_t m_in,
+                                int32_t cin, int32_t cout, void* workspace, size_t workspace_bytes, int32_t* chunks,
+                                void* stream);
+
 /* a6, a22  weight gradient of the dense per-point / per-voxel Linear layers (segformer.py:21-32,58-76,
  * point_transformer_layer.py:260-276, cosine_msa.py:58-63,403):  dw[cout][cin] = dy^T . x  over m rows.
  * Split-bf16 tall-skinny GEMM (rows = MFMA K dimension), workgroup-tiled; partial blocks per row chunk go to

@@ -23,7 +23,7 @@ int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const vo
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st);
 size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
-                       void* workspace, size_t workspace_bytes, hipStream_t st);
+                       void* workspace, size_t workspace_bytes, hipStream_t st, int32_t* chunks_out);
 
 namespace {
 
@@ -388,7 +388,7 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
     hipStream_t st = as_stream(stream);
     if (m_out > 0 && (!x || !dy || !nbr)) return SEG3D_EINVAL;
     // split-bf16: partial blocks per row chunk in the workspace, summed in a fixed order (writes all of dw)
-    if (m_out > 0 && (flags & 4)) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, workspace, workspace_bytes, st);
+    if (m_out > 0 && (flags & 4)) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, workspace, workspace_bytes, st, nullptr);
     SEG3D_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)27 * cin * cout * sizeof(float), st));
     if (m_out == 0) return SEG3D_OK;
     const int ja = pick_j(cin), jb = pick_j(cout);
@@ -398,6 +398,19 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
         case 2: return launch_wgrad_b<2>(jb, x, dy, nbr, m_out, cin, cout, dw, st);
         default: return launch_wgrad_b<1>(jb, x, dy, nbr, m_out, cin, cout, dw, st);
     }
+}
+
+/* The first half of seg3d_spconv_wgrad (split-bf16 packs only): the per-chunk partial blocks part[chunks][27 * cin * cout] are
+ * left in the workspace, *chunks (host memory) receives their count; the fixed-order sum is the caller's to queue
+ * (seg3d_reduce_partials / seg3d_reduce_partials_batched with n = nw = 27 * cin * cout), so that a backward pass sums ALL its
+ * parameter-gradient partials in one launch. */
+int seg3d_spconv_wgrad_partials(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int64_t m_in, int32_t cin,
+                                int32_t cout, void* workspace, size_t workspace_bytes, int32_t* chunks, void* stream) {
+    if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !chunks) return SEG3D_EINVAL;
+    *chunks = 0;
+    if (m_out == 0) return SEG3D_OK;
+    if (!x || !dy || !nbr) return SEG3D_EINVAL;
+    return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, nullptr, workspace, workspace_bytes, as_stream(stream), chunks);
 }
 
 }  // extern "C"

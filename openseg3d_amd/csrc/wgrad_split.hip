@@ -358,8 +358,9 @@ size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout) {
     return ((size_t)p.chunks * 27 * (size_t)cin * cout + 64) * sizeof(float);
 }
 
+// dw == nullptr: the partial blocks only (their fixed-order sum is queued by the caller); *chunks_out = their count
 int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
-                       void* workspace, size_t workspace_bytes, hipStream_t st) {
+                       void* workspace, size_t workspace_bytes, hipStream_t st, int32_t* chunks_out) {
     if (workspace_bytes < wgrad_split_sparse_workspace_bytes(m_out, cin, cout) || !workspace) return SEG3D_EINVAL;
     const Plan p = plan(m_out, cin, cout);
     float* part = static_cast<float*>(workspace);
@@ -379,6 +380,8 @@ int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int6
                            (int)p.rows, p.nbi, tiles, units, part);
     }
     SEG3D_CHECK_LAUNCH();
+    if (chunks_out) *chunks_out = p.chunks;
+    if (!dw) return SEG3D_OK;
     const int64_t n = (int64_t)27 * cin * cout;
     return wgrad_chunk_reduce(part, p.chunks, n, n, dw, nullptr, st);
 }

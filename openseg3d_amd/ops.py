@@ -811,8 +811,16 @@ class _SparseConvFn(torch.autograd.Function):
             dw = torch.empty_like(weight, dtype=torch.float32)
             ws_bytes = _lib.query("seg3d_spconv_wgrad_workspace_bytes", dy.shape[0], cin, cout)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dy.device)
-            _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
-                      _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, fk.fork(ws, dy, x, ctx.nbr))
+            if _precision_flag() & PACK_SPLIT_BF16:
+                # partial blocks now; their fixed-order sum joins the pass's other parameter-gradient sums (one launch)
+                chunks = ctypes.c_int32(0)
+                _lib.call("seg3d_spconv_wgrad_partials", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
+                          _ptr(ws), ws_bytes, ctypes.byref(chunks), fk.fork(ws, dy, x, ctx.nbr))
+                n = 27 * cin * cout
+                fk.add_reduce(ws, chunks.value, n, n, dw.data_ptr(), 0, ws)
+            else:
+                _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
+                          _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, fk.fork(ws, dy, x, ctx.nbr))
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight, ctx.t_flags)
             dx = _conv_apply(dy, ctx.nbr_t, wt, None, cout, cin, ctx.order_t, ctx.plan_t)
