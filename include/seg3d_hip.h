@@ -212,6 +212,13 @@ int32_t seg3d_spconv_tiled_supported(int32_t cin, int32_t cout);
 int seg3d_spconv_fwd_tiled(const float* x, const int32_t* nbr, const void* plan, int64_t m_out, int64_t m_in,
                            const void* w_packed, int32_t pack_flags, const float* bias /*or NULL*/,
                            const float* addend /*or NULL*/, int32_t relu, int32_t cin, int32_t cout, float* y, void* stream);
+/* The tiled schedule with the feature maps STORED in bf16 -- seg3d_spconv_fwd_act_bf16's contract (opt-in storage mode,
+ * BASELINE configs[4]): x float32 (x_bf16 = 0) or bf16 (x_bf16 = 1) rows, y and the residual addend bf16 [m_out, cout].  bf16
+ * rows stage only a hi image (half the bytes) and take two MFMAs per product. */
+int seg3d_spconv_fwd_tiled_bf16(const void* x, int32_t x_bf16, const int32_t* nbr, const void* plan, int64_t m_out,
+                                int64_t m_in, const void* w_packed, int32_t pack_flags, const float* bias /*or NULL*/,
+                                const void* addend_bf16 /*or NULL*/, int32_t relu, int32_t cin, int32_t cout, void* y_bf16,
+                                void* stream);
 /* Test hook: force the column-block width (x16 columns) of the split-bf16 gather-GEMM so that every kernel
  * instantiation can be pinned against the oracle at any row count (0 = automatic choice; 1, 2, 3, 4, 6, 12).
  * Same effect as the SEG3D_CONV_NBT environment variable, which is read once when the library loads.

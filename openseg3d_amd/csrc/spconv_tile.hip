@@ -243,12 +243,19 @@ __global__ __launch_bounds__(kThreads) void plan_kernel(const uint32_t* __restri
 // one set of B loads instead of 18, and no wave loads a B fragment another wave loads too; the four partial tiles are
 // summed through LDS in a fixed order at the end (so this layout is deterministic but not bit-identical to the per-pair
 // gather kernel, whose rows accumulate offset by offset).
-template <int WR, int WC, int NBW, bool KS = false>
-__global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* __restrict__ x, const int32_t* __restrict__ nbr,
+// IO: storage of the rows, as in spconv_split_kernel -- 0 = float32 in / out; 1 = float32 in, bf16 out; 2 = bf16 in / out (the
+// opt-in bf16-storage mode of the sparse-conv feature maps, BASELINE configs[4]): a bf16 row is its own hi half, so only the
+// hi image is staged (half the bytes) and a product takes two MFMAs (a . w_hi + a . w_lo) instead of three.  The residual
+// addend has the output's storage type; accumulation, bias and the activation stay float32.
+template <int WR, int WC, int NBW, bool KS = false, int IO = 0>
+__global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const void* __restrict__ x_v, const int32_t* __restrict__ nbr,
                                                                   PlanView pv, int64_t m_out, int n_tiles, int n_cg, int run,
                                                                   const u32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                                  const float* __restrict__ addend, int cin, int cout,
-                                                                  float* __restrict__ y, int relu, int dbg) {
+                                                                  const void* __restrict__ addend_v, int cin, int cout,
+                                                                  void* __restrict__ y_v, int relu, int dbg) {
+    const float* __restrict__ x = static_cast<const float*>(x_v);
+    const float* __restrict__ addend = static_cast<const float*>(addend_v);
+    float* __restrict__ y = static_cast<float*>(y_v);
     static_assert(KS ? (WR == 1 && WC == 1 && NBW <= 3) : (WR * WC == 4), "four waves");
     constexpr int RB = 8 / WR;  // 16-row blocks per wave
     __shared__ __attribute__((aligned(16))) u32x4 img[(kUMax + 1) * 8];
@@ -306,18 +313,23 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
     auto stage = [&](int cb, int n_rows, auto row_of) {
         const int n_items = n_rows * 4;
         for (int i0 = 0; i0 < n_items; i0 += kThreads * 4) {
-            f32x4 r[4][2];
+            f32x4 r[4][IO == 2 ? 1 : 2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = i0 + j * kThreads + tid;
                 const int u = i >> 2, q = i & 3;
                 const int col = cb * 32 + q * 8;
                 const int32_t row = i < n_items ? row_of(u) : -1;
-                r[j][0] = r[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                r[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (IO != 2) r[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (row >= 0 && col < cin) {
-                    const f32x4* p = reinterpret_cast<const f32x4*>(x + (int64_t)row * cin + col);
-                    r[j][0] = p[0];
-                    r[j][1] = p[1];
+                    if constexpr (IO == 2) {  // 8 bf16 = one 16-B piece
+                        r[j][0] = *reinterpret_cast<const f32x4*>(static_cast<const __bf16*>(x_v) + (int64_t)row * cin + col);
+                    } else {
+                        const f32x4* p = reinterpret_cast<const f32x4*>(x + (int64_t)row * cin + col);
+                        r[j][0] = p[0];
+                        r[j][1] = p[1];
+                    }
                 }
             }
 #pragma unroll
@@ -325,11 +337,15 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
                 const int i = i0 + j * kThreads + tid;
                 if (i < n_items) {
                     const int u = i >> 2, q = i & 3;
-                    u32x4 hi, lo;
-                    split8(r[j][0], r[j][1], &hi, &lo);
                     const int s0 = image_slot(u) ^ q;
-                    img[s0] = hi;
-                    img[s0 ^ 4] = lo;
+                    if constexpr (IO == 2) {
+                        img[s0] = __builtin_bit_cast(u32x4, r[j][0]);
+                    } else {
+                        u32x4 hi, lo;
+                        split8(r[j][0], r[j][1], &hi, &lo);
+                        img[s0] = hi;
+                        img[s0 ^ 4] = lo;
+                    }
                 }
             }
         }
@@ -344,21 +360,21 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
         {
             const uint32_t s = (dbg & 4) ? (uint32_t)lane : li[0] ^ (uint32_t)g;
             a_hi[0] = __builtin_bit_cast(bf16x8, img[s]);
-            a_lo[0] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
+            if constexpr (IO != 2) a_lo[0] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (rb + 1 < RB) {
                 const uint32_t s = (dbg & 4) ? (uint32_t)(lane + 8 * rb) : li[rb + 1] ^ (uint32_t)g;
                 a_hi[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s]);
-                a_lo[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
+                if constexpr (IO != 2) a_lo[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
             }
             if ((bmw >> rb) & 1u) {
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[S][n][0]);
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[S][n][1]);
-                    acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[rb & 1], bh, acc[rb][n], 0, 0, 0);
+                    if constexpr (IO != 2) acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[rb & 1], bh, acc[rb][n], 0, 0, 0);
                     acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rb & 1], bl, acc[rb][n], 0, 0, 0);
                     acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rb & 1], bh, acc[rb][n], 0, 0, 0);
                 }
@@ -488,6 +504,27 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
         }
     }
 
+    // one output row's NBW x 16 columns of this lane: (+ residual) -> activation -> store in the output's storage type
+    auto store_row = [&](int32_t orow, const float* v) {
+        if constexpr (IO == 0) {
+            float* yr = y + (int64_t)orow * cout + nb0 * 16 + c16;
+            const float* ar = addend ? addend + (int64_t)orow * cout + nb0 * 16 + c16 : nullptr;
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                float o = v[n];
+                if (ar) o += ar[n * 16];
+                yr[n * 16] = relu ? (o < 0.0f ? 0.0f : o) : o;  // (a NaN stays a NaN, as torch.relu)
+            }
+        } else {
+            __bf16* yb = static_cast<__bf16*>(y_v) + (int64_t)orow * cout + nb0 * 16 + c16;
+            const __bf16* ab = addend_v ? static_cast<const __bf16*>(addend_v) + (int64_t)orow * cout + nb0 * 16 + c16 : nullptr;
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                const float o = v[n] + (ab ? (float)ab[n * 16] : 0.0f);
+                yb[n * 16] = (__bf16)(relu ? (o < 0.0f ? 0.0f : o) : o);
+            }
+        }
+    };
     if constexpr (KS) {
         // sum the four waves' partial tiles in a fixed order: half the row blocks at a time through the image's memory
         // ([wave][row block][column block][lane] float4: no bank conflicts), wave w finishing row block 4 * half + w
@@ -511,14 +548,10 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
             for (int r = 0; r < 4; ++r) {
                 const int32_t orow = rows_s[(half * 4 + wave) * 16 + g * 4 + r];
                 if (orow >= 0) {
-                    float* yr = y + (int64_t)orow * cout + nb0 * 16 + c16;
-                    const float* ar = addend ? addend + (int64_t)orow * cout + nb0 * 16 + c16 : nullptr;
+                    float v[NBW];
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) {
-                        float v = sum[n][r];
-                        if (ar) v += ar[n * 16];
-                        yr[n * 16] = relu ? (v < 0.0f ? 0.0f : v) : v;
-                    }
+                    for (int n = 0; n < NBW; ++n) v[n] = sum[n][r];
+                    store_row(orow, v);
                 }
             }
         }
@@ -531,14 +564,10 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const float* _
         for (int r = 0; r < 4; ++r) {
             const int32_t orow = rows_s[(wr * RB + rb) * 16 + g * 4 + r];
             if (orow >= 0) {
-                float* yr = y + (int64_t)orow * cout + nb0 * 16 + c16;
-                const float* ar = addend ? addend + (int64_t)orow * cout + nb0 * 16 + c16 : nullptr;
+                float v[NBW];
 #pragma unroll
-                for (int n = 0; n < NBW; ++n) {
-                    float v = acc[rb][n][r];
-                    if (ar) v += ar[n * 16];
-                    yr[n * 16] = relu ? (v < 0.0f ? 0.0f : v) : v;  // (a NaN stays a NaN, as torch.relu)
-                }
+                for (int n = 0; n < NBW; ++n) v[n] = acc[rb][n][r];
+                store_row(orow, v);
             }
         }
 }
@@ -557,16 +586,23 @@ static const int g_tile_run = [] {
 }();
 
 template <int WR, int WC, int NBW, bool KS = false>
-int launch_tile(const float* x, const int32_t* nbr, const PlanView& pv, int64_t m_out, const void* wp, const float* bias,
-                const float* addend, int cin, int cout, float* y, int relu, hipStream_t st) {
+int launch_tile(const void* x, const int32_t* nbr, const PlanView& pv, int64_t m_out, const void* wp, const float* bias,
+                const void* addend, int cin, int cout, void* y, int relu, int io, hipStream_t st) {
     const int n_tiles = (int)ceil_div64(m_out, kTile);
     const int n_cg = cout / (WC * NBW * 16);
     int run = n_tiles / 64;  // ~8 runs per XCD: the tail imbalance stays below an eighth
     run = run < 1 ? 1 : (run > 16 ? 16 : run);
     if (g_tile_run > 0) run = g_tile_run;
     const unsigned grid = (unsigned)(ceil_div64(n_tiles, 8 * run) * 8 * run * n_cg);
-    hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles, n_cg, run,
-                       reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu, g_tile_dbg);
+    if (io == 1)
+        hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS, 1>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles,
+                           n_cg, run, reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu, g_tile_dbg);
+    else if (io == 2)
+        hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS, 2>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles,
+                           n_cg, run, reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu, g_tile_dbg);
+    else
+        hipLaunchKernelGGL((spconv_tile_kernel<WR, WC, NBW, KS, 0>), dim3(grid), dim3(kThreads), 0, st, x, nbr, pv, m_out, n_tiles,
+                           n_cg, run, reinterpret_cast<const u32x4*>(wp), bias, addend, cin, cout, y, relu, g_tile_dbg);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -599,8 +635,8 @@ static const int g_tile_layout = [] {
     return e ? atoi(e) : 0;
 }();
 
-int spconv_tile_fwd(const float* x, const int32_t* nbr, const void* plan, int64_t m_out, const void* wp, const float* bias,
-                    const float* addend, int cin, int cout, float* y, int relu, hipStream_t st) {
+int spconv_tile_fwd(const void* x, const int32_t* nbr, const void* plan, int64_t m_out, const void* wp, const float* bias,
+                    const void* addend, int cin, int cout, void* y, int relu, int io, hipStream_t st) {
     const int64_t n_tiles = ceil_div64(m_out, kTile);
     const PlanView pv = plan_view(const_cast<void*>(plan), n_tiles);
     int layout = tile_layout(cin, cout);
@@ -612,13 +648,13 @@ int spconv_tile_fwd(const float* x, const int32_t* nbr, const void* plan, int64_
     if (g_tile_layout == 2 && cout % 96 == 0) layout = 2;
     if (g_tile_layout == 3 && layout >= 6) layout = cout % 48 == 0 ? 3 : 4;  // narrow layers without the chunk split
     switch (layout) {
-        case 1: return launch_tile<1, 4, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
-        case 2: return launch_tile<2, 2, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
-        case 3: return launch_tile<4, 1, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
-        case 4: return launch_tile<4, 1, 2>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
-        case 5: return launch_tile<1, 4, 2>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
-        case 6: return launch_tile<1, 1, 3, true>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
-        case 7: return launch_tile<1, 1, 2, true>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, st);
+        case 1: return launch_tile<1, 4, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
+        case 2: return launch_tile<2, 2, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
+        case 3: return launch_tile<4, 1, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
+        case 4: return launch_tile<4, 1, 2>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
+        case 5: return launch_tile<1, 4, 2>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
+        case 6: return launch_tile<1, 1, 3, true>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
+        case 7: return launch_tile<1, 1, 2, true>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
         default: return SEG3D_EINVAL;
     }
 }
@@ -673,7 +709,19 @@ int seg3d_spconv_fwd_tiled(const float* x, const int32_t* nbr, const void* plan,
     if (m_out < 0 || m_in < 0 || !w_packed || !(pack_flags & 4) || tile_layout(cin, cout) == 0) return SEG3D_EINVAL;
     if (m_out == 0) return SEG3D_OK;
     if (!x || !nbr || !plan || !y || m_out >= (int64_t)0x7FFFFFF0) return SEG3D_EINVAL;
-    return spconv_tile_fwd(x, nbr, plan, m_out, w_packed, bias, addend, cin, cout, y, relu ? 1 : 0, as_stream(stream));
+    return spconv_tile_fwd(x, nbr, plan, m_out, w_packed, bias, addend, cin, cout, y, relu ? 1 : 0, 0, as_stream(stream));
+}
+
+/* The tiled schedule with the feature maps STORED in bf16 (seg3d_spconv_fwd_act_bf16's contract: x float32 (x_bf16 = 0) or
+ * bf16 (x_bf16 = 1) rows, y and the residual addend bf16 [m_out, cout]; accumulation, bias and activation float32). */
+int seg3d_spconv_fwd_tiled_bf16(const void* x, int32_t x_bf16, const int32_t* nbr, const void* plan, int64_t m_out, int64_t m_in,
+                                const void* w_packed, int32_t pack_flags, const float* bias, const void* addend_bf16,
+                                int32_t relu, int32_t cin, int32_t cout, void* y_bf16, void* stream) {
+    if (m_out < 0 || m_in < 0 || !w_packed || !(pack_flags & 4) || tile_layout(cin, cout) == 0) return SEG3D_EINVAL;
+    if (m_out == 0) return SEG3D_OK;
+    if (!x || !nbr || !plan || !y_bf16 || m_out >= (int64_t)0x7FFFFFF0) return SEG3D_EINVAL;
+    return spconv_tile_fwd(x, nbr, plan, m_out, w_packed, bias, addend_bf16, cin, cout, y_bf16, relu ? 1 : 0, x_bf16 ? 2 : 1,
+                           as_stream(stream));
 }
 
 }  // extern "C"

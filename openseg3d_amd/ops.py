@@ -767,6 +767,11 @@ def conv_act(x, nbr, packed, bias, cin, cout, order=None, addend=None, relu=True
         m_out = nbr.shape[1]
         y = torch.empty((m_out, cout), dtype=torch.bfloat16, device=x.device)
         res = None if addend is None else addend.to(torch.bfloat16).contiguous()
+        if _tiled_fits(plan, packed, cin, cout):
+            _lib.call("seg3d_spconv_fwd_tiled_bf16", _ptr(xin), int(xin.dtype == torch.bfloat16), _ptr(plan.nbr), _ptr(plan.data),
+                      plan.m, xin.shape[0], _ptr(packed.data), packed.flags, _ptr(bias), _ptr(res), int(bool(relu)), cin, cout,
+                      _ptr(y), _stream())
+            return y
         _lib.call("seg3d_spconv_fwd_act_bf16", _ptr(xin), int(xin.dtype == torch.bfloat16), _ptr(nbr), m_out, xin.shape[0],
                   _ptr(packed.data), packed.flags, _ptr(bias), _ptr(res), int(bool(relu)), cin, cout, _ptr(y), _ptr(order),
                   _stream())

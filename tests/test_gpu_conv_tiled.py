@@ -207,3 +207,40 @@ def test_tiled_conv_matches_the_fp64_oracle(dev):
     assert float((out.features.detach().cpu().double() - y_ref.detach()).abs().max()) < 1e-4
     out.features.backward(g.float().to(dev))
     assert float((xin.grad.cpu().double() - x.grad).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout", [(96, 192), (192, 96), (64, 48), (96, 32), (384, 384)])
+def test_tiled_bf16_storage_matches_the_fp32_storage_kernel(dev, monkeypatch, cin, cout):
+    """Opt-in bf16 storage of the feature maps through the tile schedule (seg3d_spconv_fwd_tiled_bf16; BASELINE configs[4]):
+    accumulation, bias and activation stay float32, so from float32 rows the output is the float32-storage output rounded
+    to bf16, and from bf16 rows (their own hi half: only a hi image is staged, two MFMAs per product) it is the
+    float32-storage kernel's result on the same, exactly representable rows -- within one bf16 ulp; and the tiled bf16
+    kernels agree with the per-pair bf16 kernels bit for bit wherever the tiled layout keeps their summation order."""
+    from openseg3d_amd import ops, spconv
+    coords, shape, bs = _CASES["scene"]()
+    lvl = spconv.SiteLevel(torch.from_numpy(coords).to(dev), shape, bs)
+    nbr, plan = lvl.subm(), lvl.subm_plan()
+    assert plan is not None
+    m = coords.shape[0]
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(m, cin, generator=gen).to(dev)
+    w = (torch.randn(cout, 3, 3, 3, cin, generator=gen) / (8 * cin) ** 0.5).to(dev)
+    bias = torch.randn(cout, generator=gen).to(dev)
+    res = torch.randn(m, cout, generator=gen).to(dev)
+    packed = ops.pack_weight(w, ops.PACK_FWD, use_registry=False)
+    with torch.no_grad():
+        for xin, round_inputs in ((x, False), (x, True), (x.bfloat16(), True)):
+            monkeypatch.setattr(ops, "STORAGE_ROUND_INPUTS", round_inputs)
+            for addend, relu in ((None, False), (res, True)):
+                monkeypatch.setattr(ops, "STORAGE", "fp32")
+                x_ref = xin.bfloat16().float() if round_inputs else xin.float()
+                ref = ops.conv_act(x_ref, nbr, packed, bias, cin, cout, None,
+                                   None if addend is None else addend.bfloat16().float(), relu, plan=plan)
+                monkeypatch.setattr(ops, "STORAGE", "bf16")
+                got = ops.conv_act(xin, nbr, packed, bias, cin, cout, None, addend, relu, plan=plan)
+                old = ops.conv_act(xin, nbr, packed, bias, cin, cout, None, addend, relu, plan=None)
+                assert got.dtype == torch.bfloat16 and ref.dtype == torch.float32
+                ulp = ref.abs().clamp(min=1e-30) * 2.0 ** -8
+                assert bool(((got.float() - ref).abs() <= ulp + 1e-6).all()), (str(xin.dtype), relu)
+                if cout not in (32, 48):  # (the chunk-split layouts sum in another order)
+                    assert torch.equal(got, old), (str(xin.dtype), relu)
