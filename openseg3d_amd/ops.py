@@ -254,21 +254,21 @@ def _process_group_exists():
 def _defer_join(fk, grads):
     if torch.is_grad_enabled() or not grads or _DEFER_PROBE["ok"] is False or _process_group_exists():
         return False
-    key, st = _state_for(fk)
+    st = _DEFERRED.get(_state_key(fk.device))  # (made below, only once something is really deferred)
     bases = [w if w._base is None else w._base for w, _ in grads]
-    if any(base.data_ptr() in st["seen"] for base in bases):
+    if st is not None and any(base.data_ptr() in st["seen"] for base in bases):
         st["twice"].update(base.data_ptr() for base in bases)  # second use: this call joins now, the engine sums
         return False
     for base in bases:
         if (not base.is_leaf or base.grad is not None or base._backward_hooks or not base.is_contiguous()
                 or getattr(base, "_post_accumulate_grad_hooks", None)):
             return False
-    if st["side"] is None:  # first deferral of this graph task: its final callback completes the record
+    if st is None:  # first deferral of this graph task: its final callback completes the record
+        key, st = _state_for(fk)
         try:
             torch.autograd.Variable._execution_engine.queue_callback(lambda key=key: _finish_state(key))
         except RuntimeError:  # not inside a backward pass of the engine (a direct call): join now
-            if not st["jobs"]:
-                _DEFERRED.pop(key, None)
+            _DEFERRED.pop(key, None)
             return False
     for base, (w, gr) in zip(bases, grads):
         st["seen"].add(base.data_ptr())
