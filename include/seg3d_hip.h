@@ -202,7 +202,7 @@ int seg3d_spconv_fwd_presplit(const void* xs, const int32_t* nbr, int64_t m_out,
  * input row of a tile ONCE per 32-channel slice into an LDS image and feeds all 27 offsets from it (spconv_split gathers and
  * splits per (row, offset) pair: 6.5 - 17 times per row).  Results are bit-identical to seg3d_spconv_fwd_act on the same
  * operands (same products in the same order per output row).  coords [m_out, 4] (b, z, y, x) int32 are the sites the
- * table's rows belong to; nbr [27][m_out] may gather from any row set (m_in rows).  cout % 32 == 0 or cout % 48 == 0
+ * table's rows belong to; nbr [27][m_out] may gather from any row set (m_in rows).  cout a multiple of 96 or 128, or 32 / 48
  * (seg3d_spconv_tiled_supported), split-bf16 packs only; forward and dgrad (W^T pack, flipped offsets) share one plan. */
 size_t seg3d_conv_plan_bytes(int64_t m_out);
 size_t seg3d_conv_plan_workspace_bytes(int64_t m_out);

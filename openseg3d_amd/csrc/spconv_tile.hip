@@ -621,12 +621,11 @@ bool sort_scratch_bytes(int64_t n, size_t* bytes) {
 static int tile_layout(int cin, int cout) {
     if (cin <= 0 || cout <= 0 || (cin & 7) || (cout & 15)) return 0;
     if (cout % 192 == 0) return 1;  // 1 x 4 waves of 128 rows x 48 columns
+    if (cout % 128 == 0) return 5;  // 1 x 4 waves of 128 rows x 32 columns
     if (cout % 96 == 0) return 2;   // 2 x 2 waves of 64 rows x 48 columns
     if (cout == 48) return 6;       // four waves split the chunks of one 128 x 48 tile
     if (cout == 32) return 7;       // ... 128 x 32
-    if (cout % 48 == 0) return 3;   // 4 x 1 waves of 32 rows x 48 columns
-    if (cout % 32 == 0) return 4;   // 4 x 1 waves of 32 rows x 32 columns
-    return 0;
+    return 0;  // (64 columns and other widths: every layout re-stages the image per 32-column group; the per-pair kernel wins)
 }
 
 // SEG3D_TILE_LAYOUT (A/B): force a layout id where it divides cout
@@ -647,6 +646,7 @@ int spconv_tile_fwd(const void* x, const int32_t* nbr, const void* plan, int64_t
     if (g_tile_layout == 1 && cout % 192 == 0) layout = 1;
     if (g_tile_layout == 2 && cout % 96 == 0) layout = 2;
     if (g_tile_layout == 3 && layout >= 6) layout = cout % 48 == 0 ? 3 : 4;  // narrow layers without the chunk split
+    if (g_tile_layout == 4 && cout % 32 == 0) layout = 4;
     switch (layout) {
         case 1: return launch_tile<1, 4, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
         case 2: return launch_tile<2, 2, 3>(x, nbr, pv, m_out, wp, bias, addend, cin, cout, y, relu, io, st);
