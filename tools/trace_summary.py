@@ -16,7 +16,10 @@ def short(name):
 
 
 def family(n):
-    for key, fam in (("spconv_split_kernel<", "conv gather-GEMM (fwd + dgrad) / Linear"), ("spconv_fwd_kernel", "exact-fp32 point MLP"),
+    if "spconv_split_kernel<" in n and ", true," in n:
+        return "Linear forward / dX (dense rows through the gather-GEMM)"
+    for key, fam in (("spconv_tile_kernel<", "sparse conv gather-GEMM (fwd + dgrad)"), ("spconv_split_kernel<", "sparse conv gather-GEMM (fwd + dgrad)"),
+                     ("plan_kernel", "index build + rest"), ("morton_keys", "index build + rest"), ("spconv_fwd_kernel", "exact-fp32 point MLP"),
                      ("wgrad", "weight gradients"), ("attn", "window attention"), ("tau_reduce", "window attention"),
                      ("ln_", "LayerNorm / BatchNorm passes"), ("col_", "LayerNorm / BatchNorm passes"), ("bn_", "LayerNorm / BatchNorm passes"),
                      ("affine_act", "LayerNorm / BatchNorm passes"), ("lovasz", "criterion + kNN"), ("ce_", "criterion + kNN"),
