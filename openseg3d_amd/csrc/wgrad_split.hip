@@ -44,7 +44,11 @@ Plan plan(int64_t m, int cin, int cout) {
     const int tiles = p.nbo * p.nbi;
     // a wave should see >= ~8 steps (about a third of the rows of an offset are valid pairs): chunks of ~3000
     // rows; at least ~1000 workgroups per launch
-    int64_t chunks = m / 3072;
+    static const int rows_target = [] {
+        const char* e = getenv("SEG3D_WGRAD_SPARSE_ROWS");
+        return e ? atoi(e) : 3072;
+    }();
+    int64_t chunks = m / rows_target;
     const int64_t need = (1024 + 27 * tiles - 1) / (27 * tiles);
     if (chunks < need) chunks = need;
     if (chunks < 1) chunks = 1;
@@ -368,7 +372,18 @@ int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int6
     static const bool narrow_only = getenv("SEG3D_WGRAD_NARROW") != nullptr;  // A/B switch for profiling
     // 128-wide blocks only where they add no padding (C = 256, 384, 768; not 192 = 1.5 blocks)
     const bool fits128 = ((cin + 127) / 128) * 2 == (cin + 63) / 64 && ((cout + 127) / 128) * 2 == (cout + 63) / 64;
-    if (fits128 && !narrow_only) {
+    // ... and, padded, on the rectangular wide layers (384 <-> 192, 192 <-> 96: the strided levels' convs and the 2C -> C
+    // bottlenecks): there the compaction done once per 128 x 128 block and the halved operand re-reads outweigh the padded
+    // MFMAs (384 -> 192 inverse 274 -> 196 us, 192 -> 96 inverse 190 -> 151 us, 384 -> 192 submanifold 766 -> 719 us); square
+    // 192 x 192 (78 % padding on MFMA-heavy submanifold tables) loses: 395 -> 492 us.  SEG3D_WGRAD_WIDE_MIN=n (A/B) pads every
+    // layer with both widths >= n.
+    static const int wide_min = [] {
+        const char* e = getenv("SEG3D_WGRAD_WIDE_MIN");
+        return e ? atoi(e) : 0;
+    }();
+    const int cmin = cin < cout ? cin : cout, cmax = cin < cout ? cout : cin;
+    const bool wide_padded = (wide_min > 0 && cmin >= wide_min) || (cin != cout && cmin >= 96 && cmax >= 192);
+    if ((fits128 || wide_padded) && !narrow_only) {
         const int nbo = (cout + 127) / 128, nbi = (cin + 127) / 128, tiles = nbo * nbi;
         const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
         hipLaunchKernelGGL(wgrad_sparse_wide_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
