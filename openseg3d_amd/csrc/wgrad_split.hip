@@ -86,15 +86,26 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- pair compaction: the wave's next 64-row group is always prefetched in idx_next
+    // ---- pair compaction: the table entries of the wave's next kAhead 64-row groups are always in flight (idxq): a sparse
+    // table (strided / inverse levels: 3 - 10 of 27 entries valid) needs several groups per 32-pair step, and with one group
+    // of look-ahead every one of them but the first paid a full load latency
+    constexpr int kAhead = 4;
     int head = 0, tail = 0;  // wave-uniform ring cursors (monotonic, masked on use)
     int64_t g_row = r_begin + 64 * (int64_t)wave;
-    int32_t idx_next = g_row + lane < r_end ? nk[g_row + lane] : -1;
+    int32_t idxq[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+        const int64_t r = g_row + (int64_t)j * 64 * kWaves + lane;
+        idxq[j] = r < r_end ? nk[r] : -1;
+    }
     auto scan_group = [&]() {
-        const int32_t idx = idx_next;
+        const int32_t idx = idxq[0];
         const int64_t row = g_row + lane;
         g_row += 64 * kWaves;
-        idx_next = g_row + lane < r_end ? nk[g_row + lane] : -1;
+#pragma unroll
+        for (int j = 0; j + 1 < kAhead; ++j) idxq[j] = idxq[j + 1];
+        const int64_t rn = g_row + (int64_t)(kAhead - 1) * 64 * kWaves + lane;
+        idxq[kAhead - 1] = rn < r_end ? nk[rn] : -1;
         const unsigned long long mask = __ballot(idx >= 0);
         if (idx >= 0) {
             const int p = tail + __popcll(mask & ((1ull << lane) - 1ull));
@@ -246,9 +257,17 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const fl
     // ---- pair compaction, 256 rows per round (64 per wave); cursors are identical in every wave
     int head = 0, tail = 0, round = 0;
     int64_t g_row = r_begin;
+    // table entries of the next two rounds are in flight while this round is compacted
+    int32_t idx_n1 = g_row + 64 * wave + lane < r_end ? nk[g_row + 64 * wave + lane] : -1;
+    int32_t idx_n2 = g_row + 64 * (kWaves + wave) + lane < r_end ? nk[g_row + 64 * (kWaves + wave) + lane] : -1;
     auto scan_round = [&]() {
         const int64_t row = g_row + 64 * wave + lane;
-        const int32_t idx = row < r_end ? nk[row] : -1;
+        const int32_t idx = idx_n1;
+        idx_n1 = idx_n2;
+        {
+            const int64_t rn = row + 2 * 64 * kWaves;
+            idx_n2 = rn < r_end ? nk[rn] : -1;
+        }
         const unsigned long long mask = __ballot(idx >= 0);
         const int mine = __popcll(mask);
         int* cnt = wave_cnt[round & 1];
