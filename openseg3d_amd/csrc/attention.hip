@@ -2,6 +2,7 @@
 // kernels behind them.  Reference: flat2window -> CosineMultiheadAttention -> window2flat (swformer_utils.py:34-85,
 // point_transformer_layer.py:233-258, cosine_msa.py:115-177).
 //   forward   attention_fused.hip      persistent fused kernel, every head width (dh 6 / 12 / 24 / 48), dropout-capable
+//             attention_small.hip      exact-fp32 vector-ALU kernel, dh 6 with dropout (round 4: 101 / 96 -> 86 / 73 us per layer)
 //   backward  attention_fused_bwd.hip  two flash-style passes, dh 12 / 24 / 48
 //             attention_small.hip      exact-fp32 vector-ALU passes, dh 6 (windows of ~15 voxels: 360 vs 475 us per layer)
 // Head geometries these kernels do not take (narrow heads whose count is not a multiple of 4, head widths other than the
@@ -28,6 +29,10 @@ int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ld
                           float* dv, int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
                           hipStream_t st);
 bool attn_small_supported(int heads, int dh);  // attention_small.hip
+int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+                          const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads,
+                          int dh, const float* tau, float tau_min, float* out, float* lse, const DropoutParams& drop,
+                          hipStream_t st);
 int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                           const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
                           const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads, int dh,
@@ -85,6 +90,14 @@ int seg3d_window_attn_fwd(const float* q, const float* k, const float* v, int32_
         return SEG3D_EINVAL;
     if (!attn_fused_supported(heads, dh)) return SEG3D_EINVAL;
     if (rows_misaligned(q, k, v, ldq, ldk, ldv)) return SEG3D_EINVAL;  // rows are gathered in 16-B pieces
+    // dh 6 (stage 1: windows of ~15 voxels) WITH dropout: exact fp32 on the vector ALUs, like its backward -- one hash per key
+    // pair and thread instead of the MFMA kernel's per-fragment mask: 101 -> 86 / 96 -> 73 us per layer (shift 0 / 1).  Without
+    // dropout the two forms tie (84 / 67 against 72 / 66 us) and the fused kernel stays.  SEG3D_ATTN_SMALL_FWD=0 | 1 | 2 (A/B):
+    // never / with dropout (default) / always.
+    static const int small_fwd = getenv("SEG3D_ATTN_SMALL_FWD") ? atoi(getenv("SEG3D_ATTN_SMALL_FWD")) : 1;
+    if ((small_fwd == 2 || (small_fwd == 1 && dropout_p > 0.f)) && attn_small_supported(heads, dh) && lse)
+        return attn_small_fwd_launch(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, tile_item, n_tiles, heads, dh, tau, tau_min,
+                                     out, lse, make_dropout(dropout_p, dropout_seed), as_stream(stream));
     return attn_fused_fwd_launch(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, tile_item, n_tiles, qg_item, n_qgroups,
                                  heads, dh, tau, tau_min, out, lse, dropout_p, dropout_seed, as_stream(stream));
 }

@@ -1,5 +1,6 @@
-// a19-a21 BACKWARD for the narrowest heads (dh = 6: SWFormer stage 1, C = 48): exact-fp32 vector-ALU window attention.
-// (The forward at every head width, and the backward at dh >= 12, run on the fused MFMA kernels: attention_fused*.hip.)
+// a19-a21 for the narrowest heads (dh = 6: SWFormer stage 1, C = 48), forward and backward: exact-fp32 vector-ALU window
+// attention.  (Forward and backward at dh >= 12 run on the fused MFMA kernels: attention_fused*.hip; so did the dh-6 forward
+// until round 4 -- 68 us per layer in inference, 96 us with dropout, against 4 x 21 MB of rows to move.)
 //
 // At this stage the windows hold ~15 voxels on average and a head is 6 channels wide: a 16x16x32 MFMA tile would be
 // 3/4 padding, and the matrix-core backward loses to this form (475 vs 360 us per layer on the headline scene).
@@ -112,7 +113,94 @@ __device__ __forceinline__ void through_normalise(const Vec<DH>& x_raw, Vec<DH>*
 
 constexpr int kTile = 32;
 
-// ------------------------------------------------------------------ forward
+// ------------------------------------------------------------------ forward: out = softmax(q^.k^ / tau) (. dropout) v, LSE
+// Thread (query i, head h) of a (window, 32-token tile) item walks the window's keys 32 at a time through LDS.  Cosine scores
+// are bounded by log2e / tau: that bound is the fixed softmax maximum while exp2(-2 bound) stays a normal float (tau > ~0.036),
+// otherwise the running-maximum form -- a block-uniform choice on the device scalar tau.  The row sum is taken BEFORE the
+// dropout factor (cosine_msa.py:172-176: softmax, then F.dropout, then attn @ v).
+template <int DH>
+__global__ __launch_bounds__(256, 8) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int ldq, int ldk, int ldv,
+                                                      const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
+                                                      const int32_t* __restrict__ win_count, const int2* __restrict__ tile_item,
+                                                      int heads, const float* __restrict__ tau, float tau_min,
+                                                      float* __restrict__ out, float* __restrict__ lse, DropoutParams drop) {
+    extern __shared__ float smem[];
+    const int c = heads * DH;
+    float* kbuf = smem;
+    float* vbuf = smem + kTile * c;
+    const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
+    const int2 item = tile_item[blockIdx.x];
+    const int n = win_count[item.x], start = win_start[item.x];
+    const int qi = item.y * kTile + i;
+    const int32_t qtok = qi < n ? tok[start + qi] : -1;
+    const float tau_c = fmaxf(tau[0], tau_min);
+    const float bound = kLog2e / tau_c;  // every score (log2 domain) is <= bound
+    const bool fixed_max = bound <= 40.0f;
+    Vec<DH> qn = zero_vec<DH>(), acc = zero_vec<DH>();
+    if (qtok >= 0) {
+        qn = load_vec<DH>(q + (int64_t)qtok * ldq + h * DH);
+        normalise<DH>(&qn, bound);
+    }
+    float l = 0.f, mx = fixed_max ? bound : -INFINITY;
+    const uint32_t row_state = drop.threshold ? dropout_row_state(dropout_head_state(drop, item.x, h), qi) : 0u;
+    Vec<DH> k_next, v_next;
+    auto fetch_kv = [&](int t0) {
+        const int kj = t0 + i;
+        k_next = v_next = zero_vec<DH>();
+        if (kj < n) {
+            const int32_t kt = tok[start + kj];
+            k_next = load_vec<DH>(k + (int64_t)kt * ldk + h * DH);
+            v_next = load_vec<DH>(v + (int64_t)kt * ldv + h * DH);
+        }
+    };
+    fetch_kv(0);
+    for (int t0 = 0; t0 < n; t0 += kTile) {
+        __syncthreads();
+        {
+            Vec<DH> kk = k_next;
+            normalise<DH>(&kk, 1.0f);
+            store_vec<DH>(kbuf + i * c + h * DH, kk);
+            store_vec<DH>(vbuf + i * c + h * DH, v_next);
+        }
+        __syncthreads();
+        if (t0 + kTile < n) fetch_kv(t0 + kTile);
+        const int nk = n - t0 < kTile ? n - t0 : kTile;
+        for (int j = 0; j < nk; j += 2) {  // key pairs: one dropout hash covers (query pair) x (key pair)
+            const uint32_t bits = drop.threshold ? dropout_block_bits(row_state, dropout_key_term(t0 + j)) : 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jj = j + u;
+                if (jj < nk) {
+                    const Vec<DH> kk = load_vec<DH>(kbuf + jj * c + h * DH);
+                    const Vec<DH> vv = load_vec<DH>(vbuf + jj * c + h * DH);
+                    const float sc = dot(qn, kk);
+                    float p;
+                    if (fixed_max) {
+                        p = __builtin_amdgcn_exp2f(sc - bound);
+                    } else {
+                        const float mnew = fmaxf(mx, sc);
+                        const float resc = __builtin_amdgcn_exp2f(mx - mnew);  // (exp2(-inf) = 0 on the first key)
+                        scale<DH>(resc, &acc);
+                        l *= resc;
+                        p = __builtin_amdgcn_exp2f(sc - mnew);
+                        mx = mnew;
+                    }
+                    l += p;
+                    if (drop.threshold) p *= dropout_factor(drop, bits, qi, t0 + jj);
+                    axpy<DH>(p, vv, &acc);
+                }
+            }
+        }
+    }
+    if (qtok >= 0) {
+        scale<DH>(1.0f / l, &acc);
+        store_vec<DH>(out + (int64_t)qtok * c + h * DH, acc);
+        lse[(int64_t)qtok * heads + h] = (__builtin_amdgcn_logf(l) + mx) * kLn2;  // natural-log LSE (v_log_f32 = log2)
+    }
+}
+
+// ------------------------------------------------------------------ backward, pass Q: dq, dtau
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, int ldq, int ldk, int ldv,
@@ -166,13 +254,13 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
         }
         __syncthreads();
         if (t0 + kTile < n) fetch_kv(t0 + kTile);
-        const int nk = n - t0 < kTile ? n - t0 : kTile;
+        const int nk = n - t0 < kTile ? n - t0 : kTile;  // (block-uniform: stage-1 windows hold ~15 voxels, half a tile)
 #pragma unroll 4
-        for (int j = 0; j < kTile; ++j) {
+        for (int j = 0; j < nk; ++j) {
             const Vec<DH> kk = load_vec<DH>(kbuf + j * c + h * DH);
             const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
             const float s = dot(qn, kk);
-            const float p = j < nk ? __builtin_amdgcn_exp2f(s - l2) : 0.f;
+            const float p = __builtin_amdgcn_exp2f(s - l2);
             float dpv = dot(go, vv);
             if (drop.threshold)  // dP = D * (dO . v): the forward's dropout factor of (query qi, key t0 + j), regenerated
                 dpv *= dropout_factor(drop, dropout_bits(drop, item.x, h, qi, t0 + j), qi, t0 + j);
@@ -255,12 +343,12 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
         if (t0 + kTile < n) fetch_q(t0 + kTile);
         const int nq = n - t0 < kTile ? n - t0 : kTile;
 #pragma unroll 4
-        for (int j = 0; j < kTile; ++j) {
+        for (int j = 0; j < nq; ++j) {
             const Vec<DH> qq = load_vec<DH>(qbuf + j * c + h * DH);
             const Vec<DH> gg = load_vec<DH>(gbuf + j * c + h * DH);
             const f32x2 ld = *reinterpret_cast<const f32x2*>(lbuf + (j * heads + h) * 2);
             const float s = dot(qq, kn);
-            const float p = j < nq ? __builtin_amdgcn_exp2f(s - ld[0]) : 0.f;
+            const float p = __builtin_amdgcn_exp2f(s - ld[0]);
             float dfac = 1.0f;
             if (drop.threshold) dfac = dropout_factor(drop, dropout_bits(drop, item.x, h, t0 + j, kj), t0 + j, kj);
             const float ds = p * (dfac * dot(gg, vv) - ld[1]);  // dS = P * (D * dP - delta)
@@ -319,7 +407,19 @@ int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int l
 
 }  // namespace
 
-// used by seg3d_window_attn_bwd (attention.hip): dh 6, up to 8 heads
+int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
+                          const int32_t* win_start, const int32_t* win_count, const int32_t* tile_item, int n_tiles, int heads,
+                          int dh, const float* tau, float tau_min, float* out, float* lse, const DropoutParams& drop,
+                          hipStream_t st) {
+    if (dh != 6) return SEG3D_EINVAL;
+    const size_t smem = (size_t)2 * kTile * heads * 6 * sizeof(float);
+    hipLaunchKernelGGL(attn_small_fwd<6>, dim3((unsigned)n_tiles), dim3(32 * heads), smem, st, q, k, v, ldq, ldk, ldv, tok,
+                       win_start, win_count, reinterpret_cast<const int2*>(tile_item), heads, tau, tau_min, out, lse, drop);
+    SEG3D_CHECK_LAUNCH();
+    return SEG3D_OK;
+}
+
+// used by seg3d_window_attn_fwd / _bwd (attention.hip): dh 6, up to 8 heads
 bool attn_small_supported(int heads, int dh) { return dh == 6 && heads >= 1 && heads <= 8; }
 
 int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
