@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
     constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW, NB = C::NB;
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT, QRS = F::QRS, QP = F::QP;
     static_assert(C::UW == 1, "one (tile, head) unit per wave");
+    // the spare channel of the score product (attn_common.hpp: kSpareOne / kSpareMask): channel DHS = fragment SP_KS,
+    // lane group SP_G, element 0 -- keys past the window's end are switched off inside the score MFMAs
+    constexpr int SP_KS = DHS / 32, SP_G = (DHS % 32) / 8;
+    static_assert(KS * 32 > DHS, "the score product needs a spare K channel");
     __shared__ __attribute__((aligned(16))) char lds[F::kBytes];
     constexpr int NBUF = F::NBUF;
     char* const q_lds = lds + NBUF * C::kTile;
@@ -282,6 +286,8 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
         *lo = __builtin_bit_cast(bf16x8, (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
     };
 
+    const uint32_t spare_mask = g == SP_G ? kSpareMask : 0u;
+    const uint32_t drop_shift = dropout_lane_shift_query(c16 & 1);  // (queries q0 + 16 jj + c16: q0 is a multiple of 32)
     // this wave's unit inside an item: narrow = head `wave` of the 32-query tile, wide = query tile `wave` of the head
     const int qt = C::kNarrow ? 0 : wave;
     const int hh = C::kNarrow ? wave : 0;
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
                         a = *reinterpret_cast<const u32x4*>(p);
                         b = *reinterpret_cast<const u32x4*>(p + F::kQPlane);
                     }
+                    if (s == SP_KS && g == SP_G) a[0] = kSpareOne;  // the queries' 1.0 in the spare score channel
                     q_hi[jj][s] = __builtin_bit_cast(bf16x8, a);
                     q_lo[jj][s] = __builtin_bit_cast(bf16x8, b);
                 }
@@ -422,6 +429,14 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
                         for (int s = 0; s < KS; ++s) read_k(base, hh, u, s, &k_hi[u][s], &k_lo[u][s]);
 #pragma unroll
                     for (int b = 0; b < NB; ++b) read_vt(base, hh, b, &v_hi[b], &v_lo[b]);
+                    if (last) {  // (wave-uniform) keys past the end: -16384 in the spare channel, against the queries' 1.0
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            u32x4 w = __builtin_bit_cast(u32x4, k_hi[u][SP_KS]);
+                            w[0] |= t * 32 + u * 16 + c16 >= n ? spare_mask : 0u;
+                            k_hi[u][SP_KS] = __builtin_bit_cast(bf16x8, w);
+                        }
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         if (jj == 1 && !two) break;
@@ -439,17 +454,7 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
                         if constexpr (FIXED) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
-                            if (last) {
-#pragma unroll
-                                for (int i = 0; i < 8; ++i)
-                                    if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = 0.f;
-                            }
                         } else {
-                            if (last) {
-#pragma unroll
-                                for (int i = 0; i < 8; ++i)
-                                    if (t * 32 + (i >> 2) * 16 + g * 4 + (i & 3) >= n) sc[i] = -INFINITY;
-                            }
                             float tmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
                             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, SEG3D_WAVE));
                             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, SEG3D_WAVE));
@@ -467,7 +472,6 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
                         if constexpr (DROPOUT) {
                             // keys 4g .. 4g+3 of each 16-key half = two 2 x 2 blocks shared with lane c16 ^ 1 (same query pair):
                             // the even lane hashes the first, the odd lane the second, one DPP swap (dropout_pair_bits)
-                            const int qi = q0 + 16 * jj + c16;
                             const bool odd = c16 & 1;
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
@@ -475,9 +479,10 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
                                 uint32_t bits[2];
                                 dropout_pair_bits(dropout_block_bits(drop_row[jj], dropout_key_term(kj + (odd ? 2 : 0))), odd, &bits[0], &bits[1]);
 #pragma unroll
-                                for (int r2 = 0; r2 < 2; ++r2) {
-                                    if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2)) sc[u * 4 + 2 * r2] = 0.f;
-                                    if (dropout_dropped(drop, bits[r2], qi, kj + 2 * r2 + 1)) sc[u * 4 + 2 * r2 + 1] = 0.f;
+                                for (int r2 = 0; r2 < 2; ++r2) {  // the query's parity shifted out once per hash: constant byte selects
+                                    const uint32_t adj = bits[r2] >> drop_shift;
+                                    if (dropout_dropped_byte(drop, adj, 0)) sc[u * 4 + 2 * r2] = 0.f;
+                                    if (dropout_dropped_byte(drop, adj, 1)) sc[u * 4 + 2 * r2 + 1] = 0.f;
                                 }
                             }
                         }

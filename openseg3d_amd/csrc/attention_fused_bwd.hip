@@ -16,6 +16,7 @@
 // the two tr-reads deliver).  The gradient through the normalisation is applied in the epilogue from the raw row.
 // Every wave owns its output rows; dtau = one plain store per wave, summed in a fixed order: no atomics, bit-reproducible.
 #include <cstdlib>
+#include <type_traits>
 
 #include "attn_fused.hpp"
 
@@ -64,8 +65,14 @@ __device__ __forceinline__ void through_normalise(const float* __restrict__ xrow
 
 // waves per SIMD the register allocator must leave room for (spill-free points; pass KV holds two accumulator sets:
 // at dh 48 that is one wave per SIMD, accumulators in AGPRs)
+#ifndef SEG3D_BWD_Q_WAVES  // (A/B: resident waves per SIMD of pass Q at dh <= 24 / dh 48)
+#define SEG3D_BWD_Q_WAVES 3
+#endif
+#ifndef SEG3D_BWD_Q48_WAVES
+#define SEG3D_BWD_Q48_WAVES 2
+#endif
 template <int DH, int MODE>
-constexpr int kBwdWaves = (DH <= 12 && MODE == 0) ? 3 : (DH == 48 && MODE == 1) ? 1 : 2;
+constexpr int kBwdWaves = (DH <= 24 && MODE == 0) ? SEG3D_BWD_Q_WAVES : (DH == 48 && MODE == 1) ? 1 : (DH == 48) ? SEG3D_BWD_Q48_WAVES : 2;
 
 template <int DH, int MODE>
 __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
@@ -79,6 +86,10 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     constexpr int HG = C::HG, QT = C::QT, DHS = C::DHS, KS = C::KS, VW = C::VW;
     constexpr int KRS = C::KRS, VRS = C::VRS, CT = C::CT;
     constexpr int NBQ = (DH + 15) / 16;  // 16-row d-blocks of a gradient
+    // the spare channel of the score product (attn_common.hpp: kSpareOne / kSpareMask): channel DHS = fragment SP_KS,
+    // lane group SP_G, element 0
+    constexpr int SP_KS = DHS / 32, SP_G = (DHS % 32) / 8;
+    static_assert(KS * 32 > DHS, "the score product needs a spare K channel");
     static_assert(C::UW == 1, "one (tile, head) unit per wave");
     // stationary side (this workgroup's own tokens): two images [row][head][DHS] (hi | lo planes each) that all 256 threads
     // fill with whole 16-B pieces of the rows -- as the forward stages its queries -- plus token / LSE / delta per row
@@ -126,6 +137,9 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const int st_ld = MODE == 0 ? (st_which == 0 ? ldk : ldv) : (st_which == 0 ? ldq : c_all);
     const int st_col = C::kNarrow ? (h0 + C::HPT * st_part) * DH : h0 * DH + st_part * CT;
     const float st_scale = MODE == 0 ? 1.0f : qscale;
+    // Dropout's 1 / keep factor rides on dO (image B of pass KV, the stationary dO image of pass Q): dP' = dP / keep and
+    // dV = (keep-masked P)^T dO', so the elementwise part of both passes only SELECTS (no per-element factor)
+    const float st_bscale = (MODE == 1 && drop.threshold) ? drop.inv_keep : 1.0f;
     float st_reg[CT];
     float st_lse = 0.f, st_delta = 0.f;
     auto load_tok = [&](int t) {
@@ -200,8 +214,8 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 uint32_t hi[VW / 2], lo[VW / 2];
 #pragma unroll
                 for (int i = 0; i < VW / 2; ++i) {
-                    const float a = 2 * i < DH ? st_reg[2 * i] : 0.f;
-                    const float b = 2 * i + 1 < DH ? st_reg[2 * i + 1] : 0.f;
+                    const float a = 2 * i < DH ? st_reg[2 * i] * st_bscale : 0.f;
+                    const float b = 2 * i + 1 < DH ? st_reg[2 * i + 1] * st_bscale : 0.f;
                     split2(a, b, &hi[i], &lo[i]);
                 }
                 char* p = dst + (st_part * VW) * 2;
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 #pragma unroll
                 for (int i = 0; i < CT / 2; ++i) {
                     uint32_t hi, lo;
-                    split2(st_reg[2 * i], st_reg[2 * i + 1], &hi, &lo);
+                    split2(st_reg[2 * i] * st_bscale, st_reg[2 * i + 1] * st_bscale, &hi, &lo);
                     *reinterpret_cast<uint32_t*>(p + 4 * i) = hi;
                     *reinterpret_cast<uint32_t*>(p + C::kPlane + 4 * i) = lo;
                 }
@@ -232,7 +246,9 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 const int hh = C::kNarrow ? st_part : 0;
                 if (C::kNarrow || st_part == 0) {
                     float* ld = ld_lds + buf * 2 * HG * 32;
-                    ld[hh * 32 + st_key] = st_lse * kLog2e;
+                    // a streamed query past the window's end (a clamped copy of the last row) gets an LSE no score reaches:
+                    // p = exp2(s - 3e38) = 0 exactly, so its dS and P columns vanish without a per-element mask
+                    ld[hh * 32 + st_key] = t_of * 32 + st_key < n ? st_lse * kLog2e : 3.0e38f;
                     ld[HG * 32 + hh * 32 + st_key] = dsum;
                     if (drop.threshold && (st_key & 1) == 0)
                         rs_lds[(buf * HG + hh) * 16 + (st_key >> 1)] =
@@ -279,6 +295,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         const int a_ld = MODE == 0 ? ldq : ldk;
         const float* b_src = MODE == 0 ? dout : v;
         const int b_ld = MODE == 0 ? c_all : ldv;
+        const float sb_scale = (MODE == 0 && drop.threshold) ? drop.inv_keep : 1.0f;  // dO' = dO / keep (delta below takes the raw rows)
         float ra[SP][CT], rb[SP][CT], ro[MODE == 0 ? SP : 1][CT];
         int32_t stok[SP];
         float slse[SP];
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 #pragma unroll
                     for (int i = 0; i < DHS / 2; ++i) {
                         const float a0 = 2 * i < DH ? ra[p][2 * i] * r : 0.f, a1 = 2 * i + 1 < DH ? ra[p][2 * i + 1] * r : 0.f;
-                        const float b0 = 2 * i < DH ? rb[p][2 * i] : 0.f, b1 = 2 * i + 1 < DH ? rb[p][2 * i + 1] : 0.f;
+                        const float b0 = 2 * i < DH ? rb[p][2 * i] * sb_scale : 0.f, b1 = 2 * i + 1 < DH ? rb[p][2 * i + 1] * sb_scale : 0.f;
                         split2(a0, a1, &hi[i], &lo[i]);
                         split2(b0, b1, &bhi[i], &blo[i]);
                     }
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     for (int i = 0; i < CT / 2; ++i) {
                         uint32_t hi, lo, bhi, blo;
                         split2(ra[p][2 * i] * r, ra[p][2 * i + 1] * r, &hi, &lo);
-                        split2(rb[p][2 * i], rb[p][2 * i + 1], &bhi, &blo);
+                        split2(rb[p][2 * i] * sb_scale, rb[p][2 * i + 1] * sb_scale, &bhi, &blo);
                         *reinterpret_cast<uint32_t*>(da + (st_part * CT) * 2 + 4 * i) = hi;
                         *reinterpret_cast<uint32_t*>(da + kSPlane + (st_part * CT) * 2 + 4 * i) = lo;
                         *reinterpret_cast<uint32_t*>(db + (st_part * CT) * 2 + 4 * i) = bhi;
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     };
 
     f32x4 acc0[2][NBQ], acc1[MODE == 1 ? 2 : 1][NBQ];  // MODE 0: dQ^^T; MODE 1: dK^^T (acc0) and dV^T (acc1)
-    float tau_acc[2] = {0.f, 0.f};
+    f32x2 tau2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -411,9 +428,17 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
             acc0[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (MODE == 1) acc1[j][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    // dropout: the parity of the lane's stationary token picks a byte pair of every block hash (attn_dropout.hpp)
+    const uint32_t drop_shift = MODE == 0 ? dropout_lane_shift_query(c16 & 1) : dropout_lane_shift_key(c16 & 1);
+    // the spare score channel of a streamed key past the window's end (pass Q; lanes of group SP_G only)
+    const uint32_t spare_mask = g == SP_G ? kSpareMask : 0u;
 
     // ---------------------------------------------------------------- one streamed tile
-    auto tile_step = [&](int t, int buf) {
+    // The elementwise part works on float PAIRS (the two accumulator registers of one hash block): packed subtract /
+    // multiply / fma (v_pk_*_f32: two lanes' worth per issue slot), dropout as a select on dP and P, no masks -- tokens past
+    // the window's end are switched off inside the score product (pass Q: spare channel) or by their LSE (pass KV).
+    auto tile_step = [&](int t, int buf, auto drop_tag) {
+        constexpr bool DROP = decltype(drop_tag)::value;
         const char* base = lds + buf * C::kTile;
         const bool last = t + 1 == n_t;
         bf16x8 ra_hi[2][KS], ra_lo[2][KS], rb_hi[2][KS], rb_lo[2][KS];  // row fragments of images A and B
@@ -425,6 +450,16 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 read_arow(base, u, s, &ra_hi[u][s], &ra_lo[u][s]);
                 read_brow(base, u, s, &rb_hi[u][s], &rb_lo[u][s]);
             }
+        if constexpr (MODE == 0) {
+            if (last) {  // (wave-uniform) keys past the end: -16384 in the spare channel, against the queries' 1.0
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    u32x4 w = __builtin_bit_cast(u32x4, ra_hi[u][SP_KS]);
+                    w[0] |= t * 32 + u * 16 + c16 >= n ? spare_mask : 0u;
+                    ra_hi[u][SP_KS] = __builtin_bit_cast(bf16x8, w);
+                }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NBQ; ++b) {
             read_tr(base, KRS, hh * DHS + 16 * b, &ta_hi[b], &ta_lo[b]);
@@ -442,7 +477,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) break;
-            float pv[8], dsv[8];
+            f32x2 pv[4], dsv[4];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
@@ -452,8 +487,8 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     s_acc = mfma3(ra_hi[u][s], ra_lo[u][s], a_hi[j][s], a_lo[j][s], s_acc);
                     p_acc = mfma3(rb_hi[u][s], rb_lo[u][s], b_hi[j][s], b_lo[j][s], p_acc);
                 }
-                float dfac[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop.threshold) {  // the forward's dropout factors, regenerated (wave-uniform branch)
+                uint32_t adj[2] = {0u, 0u};
+                if constexpr (DROP) {  // the forward's dropout mask, regenerated
                     // streamed tokens 4g .. 4g+3 of this 16-token half = two 2 x 2 blocks shared with lane c16 ^ 1 (same
                     // stationary pair): the even lane hashes the first, the odd lane the second, one DPP swap
                     const bool odd = c16 & 1;
@@ -463,33 +498,49 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     else mine = dropout_block_bits(rs_lds[(buf * HG + hh) * 16 + u * 8 + 2 * g + (odd ? 1 : 0)], drop_st[j]);
                     uint32_t bits[2];
                     dropout_pair_bits(mine, odd, &bits[0], &bits[1]);
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2) {
-                        const int st_i = s0 + 16 * j + c16, sm_i = sm0 + 2 * r2;
-                        const int qi_ = MODE == 0 ? st_i : sm_i, kj_ = MODE == 0 ? sm_i : st_i;
-                        dfac[2 * r2] = dropout_factor(drop, bits[r2], qi_, kj_);
-                        dfac[2 * r2 + 1] = MODE == 0 ? dropout_factor(drop, bits[r2], qi_, kj_ + 1) : dropout_factor(drop, bits[r2], qi_ + 1, kj_);
-                    }
+                    adj[0] = bits[0] >> drop_shift;
+                    adj[1] = bits[1] >> drop_shift;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float lrow = MODE == 0 ? lq[j] : l4[u][r];
-                    const float drow = MODE == 0 ? dl[j] : d4[u][r];
-                    float p = __builtin_amdgcn_exp2f(s_acc[r] - lrow);
-                    if (last && t * 32 + u * 16 + g * 4 + r >= n) p = 0.f;  // streamed token past the window's end
-                    const float ds = p * (dfac[r] * p_acc[r] - drow);       // dS = P (D dP - delta)
-                    dsv[u * 4 + r] = ds;
-                    if (MODE == 0) tau_acc[j] = fmaf(ds, s_acc[r], tau_acc[j]);
-                    else pv[u * 4 + r] = p * dfac[r];                        // dV = (D P)^T dO
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const f32x2 s2 = {s_acc[2 * r2], s_acc[2 * r2 + 1]};
+                    f32x2 dp2 = {p_acc[2 * r2], p_acc[2 * r2 + 1]};
+                    f32x2 e2, d2;
+                    if constexpr (MODE == 0) {  // the lane's own query: scalar operands (no register pair spent on a broadcast)
+                        e2 = (f32x2){s2[0] - lq[j], s2[1] - lq[j]};
+                        d2 = (f32x2){dl[j], dl[j]};
+                    } else {
+                        e2 = s2 - (f32x2){l4[u][2 * r2], l4[u][2 * r2 + 1]};
+                        d2 = (f32x2){d4[u][2 * r2], d4[u][2 * r2 + 1]};
+                    }
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                    f32x2 pk2 = p2;
+                    if constexpr (DROP) {
+                        // the pair's second element is the next KEY (pass Q: byte 1) or the next QUERY (pass KV: byte 2)
+                        const bool k0 = dropout_dropped_byte(drop, adj[r2], 0);
+                        const bool k1 = dropout_dropped_byte(drop, adj[r2], MODE == 0 ? 1 : 2);
+                        dp2[0] = k0 ? 0.f : dp2[0];
+                        dp2[1] = k1 ? 0.f : dp2[1];
+                        if (MODE == 1) {
+                            pk2[0] = k0 ? 0.f : p2[0];
+                            pk2[1] = k1 ? 0.f : p2[1];
+                        }
+                    }
+                    f32x2 ds2;  // dS = P (D dP - delta)
+                    if constexpr (MODE == 0) ds2 = p2 * (f32x2){dp2[0] - dl[j], dp2[1] - dl[j]};
+                    else ds2 = p2 * (dp2 - d2);
+                    dsv[u * 2 + r2] = ds2;
+                    if (MODE == 0) tau2[j] = __builtin_elementwise_fma(ds2, s2, tau2[j]);
+                    else pv[u * 2 + r2] = pk2;          // dV = (D P)^T dO
                 }
             }
             bf16x8 ds_hi, ds_lo;
-            split_frag(dsv, &ds_hi, &ds_lo);
+            split_frag2(dsv, &ds_hi, &ds_lo);
 #pragma unroll
             for (int b = 0; b < NBQ; ++b) acc0[j][b] = mfma3(ta_hi[b], ta_lo[b], ds_hi, ds_lo, acc0[j][b]);
             if constexpr (MODE == 1) {
                 bf16x8 p_hi, p_lo;
-                split_frag(pv, &p_hi, &p_lo);
+                split_frag2(pv, &p_hi, &p_lo);
 #pragma unroll
                 for (int b = 0; b < NBQ; ++b) acc1[j][b] = mfma3(tb_hi[b], tb_lo[b], p_hi, p_lo, acc1[j][b]);
             }
@@ -517,6 +568,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     bh = *reinterpret_cast<const u32x4*>(pb);
                     bl = *reinterpret_cast<const u32x4*>(pb + kSPlane);
                 }
+                if (MODE == 0 && ks == SP_KS && g == SP_G) ah[0] = kSpareOne;  // the queries' 1.0 in the spare score channel
                 a_hi[j][ks] = __builtin_bit_cast(bf16x8, ah);
                 a_lo[j][ks] = __builtin_bit_cast(bf16x8, al);
                 b_hi[j][ks] = __builtin_bit_cast(bf16x8, bh);
@@ -530,18 +582,22 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                 }
             }
         }
-        for (int t = 0; t < n_t; ++t) {
-            const bool more = t + 1 < n_t;
-            const int buf = C::NBUF == 2 ? (t & 1) : 0;
-            if (more) {
-                stage_load(tok_next);
-                if (t + 2 < n_t) tok_next = load_tok(t + 2);
+        auto main_loop = [&](auto drop_tag) {
+            for (int t = 0; t < n_t; ++t) {
+                const bool more = t + 1 < n_t;
+                const int buf = C::NBUF == 2 ? (t & 1) : 0;
+                if (more) {
+                    stage_load(tok_next);
+                    if (t + 2 < n_t) tok_next = load_tok(t + 2);
+                }
+                if (active) tile_step(t, buf, drop_tag);
+                if (C::NBUF == 1) __syncthreads();
+                if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0, t + 1);
+                __syncthreads();
             }
-            if (active) tile_step(t, buf);
-            if (C::NBUF == 1) __syncthreads();
-            if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0, t + 1);
-            __syncthreads();
-        }
+        };
+        if (drop.threshold) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -560,7 +616,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
             const float inv_tau = 1.0f / tau_c;
 #pragma unroll
             for (int b = 0; b < NBQ; ++b) acc0[j][b] = acc0[j][b] * inv_tau;
-            if (valid) tau_sum += tau_acc[j];
+            if (valid) tau_sum += tau2[j][0] + tau2[j][1];
             through_normalise<DH, NBQ>(q + (int64_t)trow * ldq + h * DH, g, acc0[j]);
         } else {
 #pragma unroll

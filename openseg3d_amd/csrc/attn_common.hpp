@@ -40,6 +40,29 @@ __device__ __forceinline__ void split_frag(const float* v, bf16x8* hi, bf16x8* l
     *lo = __builtin_bit_cast(bf16x8, l);
 }
 
+// the same from four float pairs: the low halves come out of one packed subtract per pair (v_pk_add_f32)
+__device__ __forceinline__ void split_frag2(const f32x2* v, bf16x8* hi, bf16x8* lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = pack_bf16(v[i][0], v[i][1]);
+        const f32x2 hf = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+        const f32x2 d = v[i] - hf;
+        h[i] = w;
+        l[i] = pack_bf16(d[0], d[1]);
+    }
+    *hi = __builtin_bit_cast(bf16x8, h);
+    *lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// Masking streamed tokens past a window's end INSIDE the score product: the K dimension of the score MFMAs is padded from
+// the stored head width DHS to a multiple of 32, so channel DHS is spare.  The stationary (query) fragment carries 1.0
+// there, the streamed (key) fragment kMaskScore for a token past the end and 0 otherwise: the score of such a token comes
+// out of the matrix core as -16384 + (a real row's score), exp2 of it is exactly 0 under any admissible temperature
+// (scores are bounded by log2e / tau_min = 144), and no per-element compare / select is spent on it.
+constexpr uint32_t kSpareOne = 0x3F80u;    // bf16 1.0 in element 0 of a fragment dword
+constexpr uint32_t kSpareMask = 0xC680u;   // bf16 -16384.0
+
 // acc += a . b in split-bf16 (hi*hi + hi*lo + lo*hi)
 __device__ __forceinline__ f32x4 mfma3(const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b_hi, const bf16x8& b_lo,
                                        f32x4 acc) {

@@ -84,6 +84,18 @@ __device__ __forceinline__ bool dropout_dropped(const DropoutParams& d, uint32_t
     return ((bits >> (8 * ((qi & 1) * 2 + (kj & 1)))) & 0xFFu) < d.threshold;
 }
 
+// Lane-view of a block's four mask bytes.  A lane of the attention kernels is fixed to ONE query (S^T = K.Q^T orientation:
+// forward, dQ pass) or ONE key (S = Q.K^T orientation: dK / dV pass); that coordinate's parity selects a byte PAIR of every
+// block's hash, the same for all of the lane's elements.  Shifting the pair down once per hash leaves byte indices that are
+// compile-time constants per element (v_cmp on a byte select instead of a variable v_bfe_u32 + v_cmp per element):
+//   query-fixed lane: adj = bits >> 16 * (qi & 1), key kj of the block reads byte (kj & 1)
+//   key-fixed lane:   adj = bits >> 8 * (kj & 1),  query qi of the block reads byte 2 * (qi & 1)
+__device__ __forceinline__ uint32_t dropout_lane_shift_query(bool query_odd) { return query_odd ? 16u : 0u; }
+__device__ __forceinline__ uint32_t dropout_lane_shift_key(bool key_odd) { return key_odd ? 8u : 0u; }
+__device__ __forceinline__ bool dropout_dropped_byte(const DropoutParams& d, uint32_t adj, int byte) {
+    return ((adj >> (8 * byte)) & 0xFFu) < d.threshold;
+}
+
 // the factor F.dropout multiplies the probability with: 0 or 1 / keep_prob
 __device__ __forceinline__ float dropout_factor(const DropoutParams& d, uint32_t bits, int qi, int kj) {
     return dropout_dropped(d, bits, qi, kj) ? 0.0f : d.inv_keep;
