@@ -246,9 +246,23 @@ def _run_reduce_jobs(jobs, device, stream):
         _lib.call("seg3d_reduce_partials_batched", _ptr(table), len(jobs), first, sp)
 
 
+# Set by dist.SceneParallel: the process's gradients are exchanged by a wrapper that reads them only AFTER the backward
+# pass (no hooks on the AccumulateGrad nodes), so deferral is safe although a process group exists.  Anything else that
+# owns a process group (torch DDP built directly, FSDP, comm hooks) leaves it False.
+DEFER_WITH_GROUP = False
+
+
 def _process_group_exists():
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized()
+    return dist.is_available() and dist.is_initialized() and not DEFER_WITH_GROUP
+
+
+def finish_deferred(device):
+    """Complete every pending deferred-join record of the device NOW (sums run, streams joined): for a caller that needs the
+    pass's gradients inside a final callback queued before the pass's own (dist.SceneParallel)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    for key in [k for k in _DEFERRED if k[1] == dev]:
+        _finish_state(key)
 
 
 def _defer_join(fk, grads):

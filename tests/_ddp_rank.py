@@ -26,7 +26,11 @@ def main():
     ds = config.DatasetSpec(cfg)
     torch.manual_seed(0)
     model = segformer.build_segmentor(cfg, ds).to(dev).train()
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False)
+    if os.environ.get("SEG3D_DDP_WRAPPER") == "native":  # dist.SceneParallel: exchange after the pass, deferred join kept
+        ddp = D.wrap_data_parallel(model, dev)
+        assert isinstance(ddp, D.SceneParallel)
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False)
     only = os.environ.get("SEG3D_DDP_ONLY_SCENE")  # single-rank reference runs: the scene of that rank
     seed = int(only) if only is not None else rank
     pts = scene.make_small_scene(20 + seed, 5000 + 1500 * seed, extent=8.0 + seed)

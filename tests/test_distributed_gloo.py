@@ -34,6 +34,7 @@ def _worker(rank, world, port, out):
     small = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
     twin = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
     twin.load_state_dict(small.state_dict())
+    os.environ["SEG3D_DDP"] = "torch"
     ddp = D.wrap_data_parallel(small, torch.device("cpu"))
     assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and not ddp.broadcast_buffers
     xs = [torch.randn(32 + 8 * r, 8, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
@@ -46,6 +47,60 @@ def _worker(rank, world, port, out):
             acc += p.grad / world
     for p, ref_g in zip(small.parameters(), want):
         assert torch.allclose(p.grad, ref_g, rtol=1e-5, atol=1e-7)
+    # the default wrapper (dist.SceneParallel: one exchange after the pass out of a flat arena): same surface, same result;
+    # rank r starts from DIFFERENT weights -- construction must broadcast rank 0's; a dict result and a parameter that
+    # takes no part in the pass; no_sync() accumulates locally
+    del os.environ["SEG3D_DDP"]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+            self.unused = torch.nn.Parameter(torch.ones(5))
+
+        def forward(self, x):
+            y = self.body(x)
+            return {"a": y, "b": y.detach(), "n": x.shape[0]}
+
+    torch.manual_seed(100 + rank)
+    net = Net()
+    sp = D.wrap_data_parallel(net, torch.device("cpu"))
+    assert isinstance(sp, D.SceneParallel) and sp.module is net
+    twin2 = Net()
+    torch.manual_seed(100)
+    ref0 = Net()  # what rank 0 drew
+    for p, q in zip(net.parameters(), ref0.parameters()):
+        assert torch.equal(p, q)
+    twin2.load_state_dict(net.state_dict())
+    sp._bucket = 40  # (elements per all-reduce slice: several slices over this small arena)
+    res = sp(xs[rank])
+    assert res["n"] == xs[rank].shape[0] and not res["b"].requires_grad
+    res["a"].square().mean().backward()
+    assert sp.exchanges == 1
+    want = [torch.zeros_like(p) for p in twin2.body.parameters()]
+    for r in range(world):
+        twin2.zero_grad()
+        twin2(xs[r])["a"].square().mean().backward()
+        for acc, p in zip(want, twin2.body.parameters()):
+            acc += p.grad / world
+    for p, ref_g in zip(net.body.parameters(), want):
+        assert torch.allclose(p.grad, ref_g, rtol=1e-5, atol=1e-7)
+    assert net.unused.grad is not None and float(net.unused.grad.abs().sum()) == 0.0
+    sp.zero_grad(set_to_none=True)
+    with sp.no_sync():
+        sp(xs[rank])["a"].square().mean().backward()
+    assert sp.exchanges == 1
+    twin2.zero_grad()
+    twin2(xs[rank])["a"].square().mean().backward()
+    for p, q in zip(net.body.parameters(), twin2.body.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-8)  # local gradient, nothing exchanged
+    sp(xs[rank])["a"].square().mean().backward()  # accumulates onto the local gradient, then exchanges the sum
+    assert sp.exchanges == 2
+    for p, ref_g in zip(net.body.parameters(), want):
+        assert torch.allclose(p.grad, 2 * ref_g, rtol=1e-5, atol=1e-7)
+    sp.eval()
+    with torch.no_grad():
+        assert sp(xs[rank])["a"].shape == (xs[rank].shape[0], 4)
     # --sync_bn: the conversion the wrapper applies first (torch admits SyncBatchNorm under DDP on GPU modules only)
     conv = D.convert_sync_bn(torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.BatchNorm1d(8)))
     assert isinstance(conv[1], torch.nn.SyncBatchNorm)

@@ -501,9 +501,9 @@ def _ddp_ranks(world, backend, env=None):
     return sorted(recs, key=lambda r: r["rank"])
 
 
-def _check_ddp_mean(recs, singles):
+def _check_ddp_mean(recs, singles, deferred=False):
     import numpy as np
-    assert all(r["n_nonfinite"] == 0 and not r["deferred_in_this_process"] for r in recs)
+    assert all(r["n_nonfinite"] == 0 and r["deferred_in_this_process"] == deferred for r in recs)
     a, b = recs
     assert a["probe"] == b["probe"] and a["total"] == b["total"]  # every rank holds the same reduced gradient
     want = (np.asarray(singles[0]["probe"]) + np.asarray(singles[1]["probe"])) / 2
@@ -521,6 +521,16 @@ def test_plain_ddp_wrapper_gets_finished_gradients():
     assert [r["probe"] for r in both] == [r["probe"] for r in off] and [r["total"] for r in both] == [r["total"] for r in off]
     singles = [_ddp_ranks(1, "gloo", {"SEG3D_DDP_ONLY_SCENE": str(r), "SEG3D_BENCH_DIST": "1"})[0] for r in range(2)]
     _check_ddp_mean(both, singles)
+
+
+def test_scene_parallel_wrapper_exchanges_after_the_pass():
+    """dist.wrap_data_parallel's default wrapper (dist.SceneParallel): nothing hangs on the AccumulateGrad nodes, the
+    backward pass keeps its deferred weight-gradient join, and ONE exchange out of a flat arena follows the pass.  Two gloo
+    ranks share the card: both end with the mean of the two single-rank gradients, with deferral ON in their processes."""
+    env = {"SEG3D_DDP_WRAPPER": "native"}
+    both = _ddp_ranks(2, "gloo", env)
+    singles = [_ddp_ranks(1, "gloo", {"SEG3D_DDP_ONLY_SCENE": str(r), "SEG3D_BENCH_DIST": "1"})[0] for r in range(2)]
+    _check_ddp_mean(both, singles, deferred=True)
 
 
 def test_two_gpus_rccl_all_reduce():
