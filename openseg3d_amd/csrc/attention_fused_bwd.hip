@@ -20,6 +20,24 @@
 
 #include "attn_fused.hpp"
 
+#ifdef SEG3D_ATTN_STAMP
+// Diagnostic build only (tools/probes/attn_bwd_stamps.py): per-wave s_memtime (100 MHz) spans of the backward passes:
+// slots [4 MODE + {0 prologue up to the first barrier, 1 main loop, 2 epilogue, 3 streamed tiles}] of wave blockIdx.x * 4 + wave
+__device__ unsigned long long* g_attn_bwd_stamp_buf = nullptr;
+extern "C" int seg3d_debug_attn_bwd_stamps(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_bwd_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : 2;
+}
+#define BSTAMP(var)                                     \
+    do {                                                \
+        __builtin_amdgcn_sched_barrier(0);              \
+        var = __builtin_amdgcn_s_memtime();             \
+        __builtin_amdgcn_sched_barrier(0);              \
+    } while (0)
+#else
+#define BSTAMP(var) do {} while (0)
+#endif
+
 namespace {
 
 using namespace attn;
@@ -63,6 +81,45 @@ __device__ __forceinline__ void through_normalise(const float* __restrict__ xrow
         for (int r = 0; r < 4; ++r) grad[b][r] = clamped ? grad[b][r] * rinv : (grad[b][r] - xr[b][r] * proj) * rinv;
 }
 
+// The same from the workgroup's own staged image: x_hat = (hi + lo) * unscale of the stationary image (q~ = q_hat log2e / tau
+// in pass Q, k_hat in pass KV; 16 - 17 significant bits, the precision of every product it enters) and rinv = 1 / max(|x|, eps)
+// as the staging thread took it -- no second gather of the raw row behind the main loop, no sqrt / divide sequence.
+// img_row = the row's hi plane at the head's first channel, `plane` bytes to the lo plane; DHS = stored channels.
+template <int DH, int DHS, int NBQ>
+__device__ __forceinline__ void through_normalise_lds(const char* img_row, int plane, float unscale, float rinv, int g, f32x4* grad) {
+    float xr[NBQ][4];
+    float proj = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBQ; ++b) {
+        const int d0 = 16 * b + 4 * g;
+        uint32_t h0 = 0u, h1 = 0u, l0 = 0u, l1 = 0u;
+        if (d0 < DHS) {
+            const uint2 hh = *reinterpret_cast<const uint2*>(img_row + d0 * 2);
+            const uint2 ll = *reinterpret_cast<const uint2*>(img_row + plane + d0 * 2);
+            h0 = hh.x; h1 = hh.y; l0 = ll.x; l1 = ll.y;
+        }
+        xr[b][0] = (__builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16)) * unscale;
+        xr[b][1] = (__builtin_bit_cast(float, h0 & 0xFFFF0000u) + __builtin_bit_cast(float, l0 & 0xFFFF0000u)) * unscale;
+        xr[b][2] = (__builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16)) * unscale;
+        xr[b][3] = (__builtin_bit_cast(float, h1 & 0xFFFF0000u) + __builtin_bit_cast(float, l1 & 0xFFFF0000u)) * unscale;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (d0 + r >= DH) {  // (stored padding channels are zero; accumulator rows past the head width carry a neighbour's products)
+                xr[b][r] = 0.f;
+                grad[b][r] = 0.f;
+            }
+            proj = fmaf(xr[b][r], grad[b][r], proj);
+        }
+    }
+    proj += __shfl_xor(proj, 16, SEG3D_WAVE);
+    proj += __shfl_xor(proj, 32, SEG3D_WAVE);
+    const bool clamped = rinv > 0.99f / kNormEps;  // |x| < eps: x_hat = x / eps, d x = d x_hat / eps
+#pragma unroll
+    for (int b = 0; b < NBQ; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) grad[b][r] = clamped ? grad[b][r] * rinv : (grad[b][r] - xr[b][r] * proj) * rinv;
+}
+
 // waves per SIMD the register allocator must leave room for (spill-free points; pass KV holds two accumulator sets:
 // at dh 48 that is one wave per SIMD, accumulators in AGPRs)
 #ifndef SEG3D_BWD_Q_WAVES  // (A/B: resident waves per SIMD of pass Q at dh <= 24 / dh 48)
@@ -97,13 +154,14 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     constexpr int SRS = HG * DHS * 2 + (DH == 48 ? 0 : 16);  // bytes per row per plane
     constexpr int kSPlane = SROWS * SRS;
     constexpr int kStreamBytes = C::NBUF * C::kTile + (MODE == 1 ? C::NBUF * (2 * HG * 32 + HG * 16) * 4 : 0);
-    constexpr int kStatBytes = 4 * kSPlane + SROWS * 4 + 2 * SROWS * HG * 4;
+    constexpr int kStatBytes = 4 * kSPlane + SROWS * 4 + 3 * SROWS * HG * 4;
     __shared__ __attribute__((aligned(16))) char lds[kStreamBytes + kStatBytes];
     char* const sa_lds = lds + kStreamBytes;            // image A: Q~ (MODE 0) / K^ (MODE 1)
     char* const sb_lds = sa_lds + 2 * kSPlane;          // image B: dO (MODE 0) / V (MODE 1)
     int32_t* const stok_lds = reinterpret_cast<int32_t*>(sb_lds + 2 * kSPlane);
     float* const slse_lds = reinterpret_cast<float*>(stok_lds + SROWS);  // MODE 0: [row][head] log2-domain LSE, then delta
     float* const sdel_lds = slse_lds + SROWS * HG;
+    float* const snrm_lds = sdel_lds + SROWS * HG;      // [row][head] 1 / max(|x|, eps) of the stationary image-A rows (epilogue)
     float* ld_lds = reinterpret_cast<float*>(lds + C::NBUF * C::kTile);  // MODE 1: [buf][L | delta][head][32 tokens]
     // MODE 1: dropout hash state of the streamed query pairs, [buf][head][16 pairs] (attn_dropout.hpp: the two-round part of
     // the hash, once per query pair and tile instead of once per 2 x 2 block and lane)
@@ -111,6 +169,10 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
+#ifdef SEG3D_ATTN_STAMP
+    unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+    BSTAMP(st_t0);
+#endif
     // Block -> (item, head group): the head groups of one item run side by side on ONE XCD (blocks are dealt round-robin
     // over the 8 XCDs, so block % 8 labels the blocks that share an L2): a head's slice of a token row is a fraction of a
     // cache line, and the groups would otherwise pull the same lines over the fabric once per XCD (see attention_fused.hip)
@@ -330,7 +392,9 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     float ss = 0.f;
 #pragma unroll
                     for (int d = 0; d < DH; ++d) ss = fmaf(ra[p][d], ra[p][d], ss);
-                    const float r = (MODE == 0 ? qscale : 1.0f) * inv_norm(ss);
+                    const float rn = inv_norm(ss);
+                    const float r = (MODE == 0 ? qscale : 1.0f) * rn;
+                    snrm_lds[row * HG + st_part] = rn;
                     uint32_t hi[DHS / 2], lo[DHS / 2], bhi[DHS / 2], blo[DHS / 2];
 #pragma unroll
                     for (int i = 0; i < DHS / 2; ++i) {
@@ -353,7 +417,9 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
 #pragma unroll
                     for (int d = 0; d < CT; ++d) ss = fmaf(ra[p][d], ra[p][d], ss);
                     ss = quad_sum(ss);
-                    const float r = (MODE == 0 ? qscale : 1.0f) * inv_norm(ss);
+                    const float rn = inv_norm(ss);
+                    const float r = (MODE == 0 ? qscale : 1.0f) * rn;
+                    if (st_part == 0) snrm_lds[row] = rn;
 #pragma unroll
                     for (int i = 0; i < CT / 2; ++i) {
                         uint32_t hi, lo, bhi, blo;
@@ -519,15 +585,17 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                         // the pair's second element is the next KEY (pass Q: byte 1) or the next QUERY (pass KV: byte 2)
                         const bool k0 = dropout_dropped_byte(drop, adj[r2], 0);
                         const bool k1 = dropout_dropped_byte(drop, adj[r2], MODE == 0 ? 1 : 2);
-                        dp2[0] = k0 ? 0.f : dp2[0];
-                        dp2[1] = k1 ? 0.f : dp2[1];
-                        if (MODE == 1) {
+                        if (MODE == 0) {
+                            dp2[0] = k0 ? 0.f : dp2[0];
+                            dp2[1] = k1 ? 0.f : dp2[1];
+                        } else {  // one select serves both products: dS = (D P) dP - P delta
                             pk2[0] = k0 ? 0.f : p2[0];
                             pk2[1] = k1 ? 0.f : p2[1];
                         }
                     }
                     f32x2 ds2;  // dS = P (D dP - delta)
                     if constexpr (MODE == 0) ds2 = p2 * (f32x2){dp2[0] - dl[j], dp2[1] - dl[j]};
+                    else if constexpr (DROP) ds2 = __builtin_elementwise_fma(pk2, dp2, -(p2 * d2));
                     else ds2 = p2 * (dp2 - d2);
                     dsv[u * 2 + r2] = ds2;
                     if (MODE == 0) tau2[j] = __builtin_elementwise_fma(ds2, s2, tau2[j]);
@@ -551,6 +619,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     {
         stage_store(0, 0);
         __syncthreads();
+        BSTAMP(st_t1);
         // this wave's stationary fragments (row fragments of both images), token, LSE and delta of its rows
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -598,6 +667,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         };
         if (drop.threshold) main_loop(std::true_type{});
         else main_loop(std::false_type{});
+        BSTAMP(st_t2);
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -611,17 +681,20 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     for (int j = 0; j < 2; ++j) {
         if (j == 1 && !two) break;
         const bool valid = token[j] >= 0;
-        const int32_t trow = valid ? token[j] : tok[start];  // invalid columns read a real row and store nothing
+        const int32_t trow = token[j];
+        const int srow = st_tile * 32 + 16 * j + c16;  // the lane's row of the stationary images (all rows were staged)
+        const char* img_row = sa_lds + srow * SRS + hh * DHS * 2;
+        const float rinv = snrm_lds[srow * HG + hh];
         if constexpr (MODE == 0) {
             const float inv_tau = 1.0f / tau_c;
 #pragma unroll
             for (int b = 0; b < NBQ; ++b) acc0[j][b] = acc0[j][b] * inv_tau;
             if (valid) tau_sum += tau2[j][0] + tau2[j][1];
-            through_normalise<DH, NBQ>(q + (int64_t)trow * ldq + h * DH, g, acc0[j]);
+            through_normalise_lds<DH, DHS, NBQ>(img_row, kSPlane, 1.0f / qscale, rinv, g, acc0[j]);
         } else {
 #pragma unroll
             for (int b = 0; b < NBQ; ++b) acc0[j][b] = acc0[j][b] * kLn2;  // Q~ = q_hat log2e / tau  ->  q_hat / tau = Q~ ln2
-            through_normalise<DH, NBQ>(k + (int64_t)trow * ldk + h * DH, g, acc0[j]);
+            through_normalise_lds<DH, DHS, NBQ>(img_row, kSPlane, 1.0f, rinv, g, acc0[j]);
         }
         if (!valid) continue;
         float* o0 = MODE == 0 ? dq + (int64_t)trow * lddq + h * DH : dk + (int64_t)trow * lddk + h * DH;
@@ -651,6 +724,17 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         for (int off = 32; off > 0; off >>= 1) tau_sum += __shfl_xor(tau_sum, off, SEG3D_WAVE);
         if (lane == 0) *tau_slot = tau[0] > tau_min ? -tau_sum * kLn2 / tau_c : 0.f;
     }
+#ifdef SEG3D_ATTN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BSTAMP(st_t3);
+    if (g_attn_bwd_stamp_buf && lane == 0) {
+        unsigned long long* o = g_attn_bwd_stamp_buf + ((size_t)blockIdx.x * 4 + wave) * 8 + 4 * MODE;
+        o[0] = st_t1 - st_t0;
+        o[1] = st_t2 - st_t1;
+        o[2] = st_t3 - st_t2;
+        o[3] = (unsigned long long)n_t;
+    }
+#endif
 }
 
 // dtau = sum of the per-wave partials in a fixed order
