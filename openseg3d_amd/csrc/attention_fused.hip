@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
+    if (tid < NBUF * 2 * 4)  // the zero block behind each plane of each key-tile buffer (never written again)
+        *reinterpret_cast<uint32_t*>(lds + (tid >> 3) * C::kTile + ((tid >> 2) & 1) * C::kPlane + C::kPlaneData + (tid & 3) * 4) = 0u;
 #ifdef SEG3D_ATTN_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -259,15 +261,13 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
 
     // ---------------------------------------------------------------- fragment reads of a staged tile
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // (lanes whose channels lie past the stored head width read the plane's zero block: no branch, no register fill)
     auto read_k = [&](const char* base, int hh, int u, int s, bf16x8* hi, bf16x8* lo) {
         const int c0 = 32 * s + 8 * g;
-        if (c0 < DHS) {
-            const char* p = base + (u * 16 + c16) * KRS + (hh * DHS + c0) * 2;
-            *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-            *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
-        } else {
-            *hi = *lo = __builtin_bit_cast(bf16x8, zero4);
-        }
+        const int rel = c0 < DHS ? (u * 16 + c16) * KRS + (hh * DHS + c0) * 2 : C::kPlaneData;
+        const char* p = base + rel;
+        *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+        *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
     };
     // V^T fragment of d-block b: A operand, lane (d = 16 b + c16, key slots 8 g .. 8 g + 7 = keys 4g..4g+3, 16+4g..16+4g+3).
     // Transposed out of the row-major image by two ds_read_b64_tr_b16 per plane: lane 4 q' + p' of a 16-lane group

@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
     BSTAMP(st_t0);
 #endif
+    if (tid < C::NBUF * 2 * 4)  // the zero block behind each plane of each streamed-tile buffer (never written again)
+        *reinterpret_cast<uint32_t*>(lds + (tid >> 3) * C::kTile + ((tid >> 2) & 1) * C::kPlane + C::kPlaneData + (tid & 3) * 4) = 0u;
     // Block -> (item, head group): the head groups of one item run side by side on ONE XCD (blocks are dealt round-robin
     // over the 8 XCDs, so block % 8 labels the blocks that share an L2): a head's slice of a token row is a fraction of a
     // cache line, and the groups would otherwise pull the same lines over the fabric once per XCD (see attention_fused.hip)
@@ -448,27 +450,19 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     }
 
     // ---------------------------------------------------------------- fragment reads of a staged tile
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     // row fragment (A operand: token u * 16 + c16, channels 32 s + 8 g .. + 7) of image A / image B
+    // (lanes whose channels lie past the stored width read the plane's zero block, attn_fused.hpp: no branch, no register fill)
     auto read_arow = [&](const char* base, int u, int s, bf16x8* hi, bf16x8* lo) {
         const int c0 = 32 * s + 8 * g;
-        if (c0 < DHS) {
-            const char* p = base + (u * 16 + c16) * KRS + (hh * DHS + c0) * 2;
-            *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-            *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
-        } else {
-            *hi = *lo = __builtin_bit_cast(bf16x8, zero4);
-        }
+        const char* p = base + (c0 < DHS ? (u * 16 + c16) * KRS + (hh * DHS + c0) * 2 : C::kPlaneData);
+        *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+        *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
     };
     auto read_brow = [&](const char* base, int u, int s, bf16x8* hi, bf16x8* lo) {
         const int c0 = 32 * s + 8 * g;
-        if (c0 < VW) {
-            const char* p = base + 32 * KRS + (u * 16 + c16) * VRS + (hh * VW + c0) * 2;
-            *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-            *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
-        } else {
-            *hi = *lo = __builtin_bit_cast(bf16x8, zero4);
-        }
+        const char* p = base + (c0 < VW ? 32 * KRS + (u * 16 + c16) * VRS + (hh * VW + c0) * 2 : C::kPlaneData);
+        *hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+        *lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + C::kPlane));
     };
     // transposed fragment of d-block b (A operand: row d = 16 b + c16, token slots 8 g .. 8 g + 7 = tokens 4g..4g+3,
     // 16+4g..16+4g+3) out of a row-major image: two ds_read_b64_tr_b16 per plane, every lane takes part

@@ -27,7 +27,10 @@ struct Cfg {
     // LDS row strides in bytes (data + padding chosen so that the fragment reads spread over the banks)
     static constexpr int KRS = HG * DHS * 2 + (kNarrow ? 16 : (DH == 24 ? 0 : 0));
     static constexpr int VRS = HG * VW * 2 + (kNarrow ? 32 : (DH == 24 ? 32 : 0));
-    static constexpr int kPlane = 32 * (KRS + VRS);    // one plane (hi or lo) of a staged key tile
+    // one plane (hi or lo) of a staged key tile + 16 zero bytes: fragment lanes whose channels lie past the stored width read
+    // THAT block (a loop-invariant address) instead of zero-filling their registers under a branch per tile
+    static constexpr int kPlaneData = 32 * (KRS + VRS);
+    static constexpr int kPlane = kPlaneData + 16;
     static constexpr int kTile = 2 * kPlane;
     static constexpr int NBUF = kNarrow ? 1 : 2;       // narrow: one buffer, more workgroups per CU
     static constexpr int CT = kNarrow ? HPT * DH : DH / 4;  // fp32 values a staging thread converts per row

@@ -7,7 +7,8 @@ usage: python tools/pmc_derived.py <dirA> <dirB> <kernel regex>
 Columns: launches, us per launch (kernel trace of pass A), matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
 duration x shader clock, the clock taken from SQ_BUSY_CYCLES / 32 shader engines / duration), non-MFMA vector / LDS /
 scalar / vector-memory-read instructions per MFMA, LDS bank-conflict cycles per active LDS cycle, share of wave cycles
-spent waiting (any / on an instruction's operands)."""
+spent waiting (any / on an instruction's operands), vector-ALU and any-instruction issue activity as a share of the SIMD
+cycles (SQ_ACTIVE_INST_* x 4; includes the MFMA issue slots)."""
 import collections
 import csv
 import glob
@@ -41,7 +42,7 @@ def main():
             for k, v in c.items():
                 o[which][k] += v
     print(f"{'kernel':34s} {'n':>4s} {'us':>8s} {'GHz':>5s} {'mfma busy':>9s} {'valu/mfma':>9s} {'lds/mfma':>8s} {'salu/mfma':>9s} "
-          f"{'vmem/mfma':>9s} {'bankconf':>8s} {'wait':>5s} {'waitinst':>8s}")
+          f"{'vmem/mfma':>9s} {'bankconf':>8s} {'wait':>5s} {'waitinst':>8s} {'valu busy':>9s} {'inst busy':>9s}")
     for key in sorted(out):
         a, b, na = out[key]["a"], out[key]["b"], max(out[key]["na"], 1)
         mf = a["SQ_INSTS_MFMA"]
@@ -55,7 +56,10 @@ def main():
         print(f"{key:34s} {na:4d} {a['ns'] / na / 1e3:8.1f} {ghz:5.2f} {busy * 100:8.1f}% {per_mfma(b['SQ_INSTS_VALU'] - mf):9.1f} "
               f"{per_mfma(b['SQ_INSTS_LDS']):8.2f} {per_mfma(b['SQ_INSTS_SALU']):9.2f} {per_mfma(b['SQ_INSTS_VMEM_RD']):9.2f} "
               f"{b['SQ_LDS_BANK_CONFLICT'] / max(b['SQ_LDS_IDX_ACTIVE'], 1):8.2f} {a['SQ_WAIT_ANY'] / max(a['SQ_WAVE_CYCLES'], 1):5.2f} "
-              f"{a['SQ_WAIT_INST_ANY'] / max(a['SQ_WAVE_CYCLES'], 1):8.2f}")
+              f"{a['SQ_WAIT_INST_ANY'] / max(a['SQ_WAVE_CYCLES'], 1):8.2f} "
+              # SQ_ACTIVE_INST_* count quad-cycles of waves issuing that instruction class (x 4 = SIMD cycles)
+              f"{a['SQ_ACTIVE_INST_VALU'] * 4 / (1024.0 * a['ns'] * ghz) * 100 if ghz > 0 else 0.0:8.1f}% "
+              f"{a['SQ_ACTIVE_INST_ANY'] * 4 / (1024.0 * a['ns'] * ghz) * 100 if ghz > 0 else 0.0:8.1f}%")
 
 
 if __name__ == "__main__":
