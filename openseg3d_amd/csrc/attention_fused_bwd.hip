@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         constexpr bool DROP = decltype(drop_tag)::value;
         const char* base = lds + buf * C::kTile;
         const bool last = t + 1 == n_t;
+        const bool u_two = n - t * 32 > 16;  // the tile's second 16-token half holds tokens (false on a window's last tile only)
         bf16x8 ra_hi[2][KS], ra_lo[2][KS], rb_hi[2][KS], rb_lo[2][KS];  // row fragments of images A and B
         bf16x8 ta_hi[NBQ], ta_lo[NBQ], tb_hi[MODE == 1 ? NBQ : 1], tb_lo[MODE == 1 ? NBQ : 1];  // transposed fragments
 #pragma unroll
@@ -540,6 +541,10 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
             f32x2 pv[4], dsv[4];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !u_two) {  // (wave-uniform) the streamed tile's second 16-token half lies past the window's end
+                    dsv[2] = dsv[3] = pv[2] = pv[3] = (f32x2){0.f, 0.f};
+                    continue;
+                }
                 f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
