@@ -10,6 +10,7 @@ SEG3D_CONV_TILED=0 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-
 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/default_b.json 2> $O/default_b.err; echo default_b rc=$?
 SEG3D_WGRAD_DEFER=0 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/nodefer.json 2> $O/nodefer.err; echo nodefer rc=$?
 SEG3D_BENCH_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/ddp1.json 2> $O/ddp1.err; echo ddp1 rc=$?
+SEG3D_DDP=torch SEG3D_BENCH_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/ddp1_torch.json 2> $O/ddp1_torch.err; echo ddp1_torch rc=$?
 python bench.py --segmentor spnet --steps 10 --warmup 3 > $O/spnet.json 2> $O/spnet.err; echo spnet rc=$?
 python tools/attn_bench.py --bwd > $O/attn.txt 2>&1; python tools/attn_bench.py --bwd --drop 0.1 >> $O/attn.txt 2>&1; echo attn rc=$?
 python tools/conv_bench.py > $O/conv_layers.txt 2>&1; echo conv rc=$?
