@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
         l2 = lse[(int64_t)qtok * heads + h] * kLog2e;
     }
     float tau_acc = 0.f;
+    // dropout: the query's share of the hash (two mixing rounds) once per thread; its parity picks the byte pair of every block
+    const uint32_t row_state = drop.threshold ? dropout_row_state(dropout_head_state(drop, item.x, h), qi) : 0u;
+    const uint32_t drop_shift = dropout_lane_shift_query(qi & 1);
     Vec<DH> k_next, v_next;
     auto fetch_kv = [&](int t0) {
         const int kj = t0 + i;
@@ -255,18 +258,26 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
         __syncthreads();
         if (t0 + kTile < n) fetch_kv(t0 + kTile);
         const int nk = n - t0 < kTile ? n - t0 : kTile;  // (block-uniform: stage-1 windows hold ~15 voxels, half a tile)
-#pragma unroll 4
-        for (int j = 0; j < nk; ++j) {
-            const Vec<DH> kk = load_vec<DH>(kbuf + j * c + h * DH);
-            const Vec<DH> vv = load_vec<DH>(vbuf + j * c + h * DH);
-            const float s = dot(qn, kk);
-            const float p = __builtin_amdgcn_exp2f(s - l2);
-            float dpv = dot(go, vv);
-            if (drop.threshold)  // dP = D * (dO . v): the forward's dropout factor of (query qi, key t0 + j), regenerated
-                dpv *= dropout_factor(drop, dropout_bits(drop, item.x, h, qi, t0 + j), qi, t0 + j);
-            const float ds = p * (dpv - delta);
-            tau_acc = fmaf(ds, s, tau_acc);
-            axpy<DH>(ds, kk, &acc);
+#pragma unroll 2
+        for (int j = 0; j < nk; j += 2) {  // key pairs: one hash covers the 2 x 2 block of (query pair) x (key pair)
+            // dP = D * (dO . v): the forward's dropout factors, regenerated; the lane's query parity is shifted out once per
+            // hash, so the pair's keys read bytes 0 and 1 (attn_dropout.hpp)
+            const uint32_t adj = drop.threshold ? dropout_block_bits(row_state, dropout_key_term(t0 + j)) >> drop_shift : 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jj = j + u;
+                if (jj < nk) {
+                    const Vec<DH> kk = load_vec<DH>(kbuf + jj * c + h * DH);
+                    const Vec<DH> vv = load_vec<DH>(vbuf + jj * c + h * DH);
+                    const float s = dot(qn, kk);
+                    const float p = __builtin_amdgcn_exp2f(s - l2);
+                    float dpv = dot(go, vv);
+                    if (drop.threshold) dpv = dropout_dropped_byte(drop, adj, u) ? 0.f : dpv * drop.inv_keep;
+                    const float ds = p * (dpv - delta);
+                    tau_acc = fmaf(ds, s, tau_acc);
+                    axpy<DH>(ds, kk, &acc);
+                }
+            }
         }
     }
     if (qtok >= 0) {
@@ -315,6 +326,10 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
         normalise<DH>(&kn, 1.0f);
         vv = load_vec<DH>(v + (int64_t)ktok * ldv + h * DH);
     }
+    // dropout: what does not depend on the streamed query -- the (window, head) state and the lane's key term
+    const uint32_t head_state = drop.threshold ? dropout_head_state(drop, item.x, h) : 0u;
+    const uint32_t key_term = dropout_key_term(kj);
+    const uint32_t drop_shift = dropout_lane_shift_key(kj & 1);
     Vec<DH> q_next, g_next, o_next;
     float lse_next = 0.f;
     auto fetch_q = [&](int t0) {
@@ -342,18 +357,26 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
         __syncthreads();
         if (t0 + kTile < n) fetch_q(t0 + kTile);
         const int nq = n - t0 < kTile ? n - t0 : kTile;
-#pragma unroll 4
-        for (int j = 0; j < nq; ++j) {
-            const Vec<DH> qq = load_vec<DH>(qbuf + j * c + h * DH);
-            const Vec<DH> gg = load_vec<DH>(gbuf + j * c + h * DH);
-            const f32x2 ld = *reinterpret_cast<const f32x2*>(lbuf + (j * heads + h) * 2);
-            const float s = dot(qq, kn);
-            const float p = __builtin_amdgcn_exp2f(s - ld[0]);
-            float dfac = 1.0f;
-            if (drop.threshold) dfac = dropout_factor(drop, dropout_bits(drop, item.x, h, t0 + j, kj), t0 + j, kj);
-            const float ds = p * (dfac * dot(gg, vv) - ld[1]);  // dS = P * (D * dP - delta)
-            axpy<DH>(p * dfac, gg, &dv_acc);                     // dV = (D * P)^T dO
-            axpy<DH>(ds, qq, &dk_acc);
+#pragma unroll 2
+        for (int j = 0; j < nq; j += 2) {  // query pairs: one hash (row state of the pair + one mixing round) per 2 x 2 block;
+            // the lane's key parity is shifted out once, the pair's queries read bytes 0 and 2 (attn_dropout.hpp)
+            const uint32_t adj = drop.threshold ? dropout_block_bits(dropout_row_state(head_state, t0 + j), key_term) >> drop_shift : 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jj = j + u;
+                if (jj < nq) {
+                    const Vec<DH> qq = load_vec<DH>(qbuf + jj * c + h * DH);
+                    const Vec<DH> gg = load_vec<DH>(gbuf + jj * c + h * DH);
+                    const f32x2 ld = *reinterpret_cast<const f32x2*>(lbuf + (jj * heads + h) * 2);
+                    const float s = dot(qq, kn);
+                    const float p = __builtin_amdgcn_exp2f(s - ld[0]);
+                    float dfac = 1.0f;
+                    if (drop.threshold) dfac = dropout_dropped_byte(drop, adj, 2 * u) ? 0.f : drop.inv_keep;
+                    const float ds = p * (dfac * dot(gg, vv) - ld[1]);  // dS = P * (D * dP - delta)
+                    axpy<DH>(p * dfac, gg, &dv_acc);                     // dV = (D * P)^T dO
+                    axpy<DH>(ds, qq, &dk_acc);
+                }
+            }
         }
     }
     if (ktok >= 0) {
