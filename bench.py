@@ -627,7 +627,8 @@ def main():
                 out["allreduce"] = {"ms_per_step_without_exchange": round(nosync_ms, 3),
                                     "exposed_ms_per_step": round(dt / args.steps * 1e3 - nosync_ms, 3),
                                     "gradient_bytes": int(sum(p.numel() for p in model.parameters()) * 4),
-                                    "note": "DDP buckets over " + dist.get_backend() + "; exposed = timed step minus the "
+                                    "wrapper": type(net).__name__,
+                                    "note": "gradient exchange over " + dist.get_backend() + "; exposed = timed step minus the "
                                             "same step under no_sync()"}
         # the attention temperature after the timed steps: below ~0.036 the kernels leave the fixed-maximum softmax
         taus = [float(p.detach()) for n, p in model.named_parameters() if n.endswith(".tau")]
