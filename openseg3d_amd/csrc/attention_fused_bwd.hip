@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const int g = lane >> 4, c16 = lane & 15;
 #ifdef SEG3D_ATTN_STAMP
     unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+    unsigned long long st_la = 0, st_lb = 0, st_lc = 0, st_lx = 0, st_compute = 0, st_wait = 0, st_store = 0, st_barrier = 0;
     BSTAMP(st_t0);
 #endif
     if (tid < C::NBUF * 2 * 4)  // the zero block behind each plane of each streamed-tile buffer (never written again)
@@ -658,10 +659,27 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
                     stage_load(tok_next);
                     if (t + 2 < n_t) tok_next = load_tok(t + 2);
                 }
+                BSTAMP(st_la);
                 if (active) tile_step(t, buf, drop_tag);
+                BSTAMP(st_lb);
                 if (C::NBUF == 1) __syncthreads();
+#ifdef SEG3D_ATTN_STAMP
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (diagnostic build) the wait for the next tile's rows, apart
+#endif
+                BSTAMP(st_lc);
                 if (more) stage_store(C::NBUF == 2 ? (buf ^ 1) : 0, t + 1);
+                BSTAMP(st_lx);
                 __syncthreads();
+#ifdef SEG3D_ATTN_STAMP
+                {
+                    unsigned long long st_le;
+                    BSTAMP(st_le);
+                    st_compute += st_lb - st_la;
+                    st_wait += st_lc - st_lb;
+                    st_store += st_lx - st_lc;
+                    st_barrier += st_le - st_lx;
+                }
+#endif
             }
         };
         if (drop.threshold) main_loop(std::true_type{});
@@ -731,6 +749,12 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         o[0] = st_t1 - st_t0;
         o[1] = st_t2 - st_t1;
         o[2] = st_t3 - st_t2;
+        // the tile loop by phase, in a second record block behind the first (8 x 4 x blocks words further)
+        unsigned long long* o2 = g_attn_bwd_stamp_buf + ((size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4 + wave) * 8 + 4 * MODE;
+        o2[0] = st_compute;
+        o2[1] = st_wait;
+        o2[2] = st_store;
+        o2[3] = st_barrier;
         o[3] = (unsigned long long)n_t;
     }
 #endif

@@ -46,9 +46,18 @@ def main():
                 qk.grad = v.grad = None
                 torch.cuda.synchronize()
             s = buf.view(-1, 4, 8).double()
+            # grid of both passes (attention_fused_bwd.hip: bwd_blocks): whole groups of 8 items x head groups; the tile loop's
+            # phase sums sit in a second record block `grid` workgroups further
+            n_items, hgn = (wi.n_tiles, 2) if c // 8 <= 12 else (wi.n_qgroups, 8)
+            grid = (n_items + 7) // 8 * 8 * hgn
             for mode, name in ((0, "pass Q "), (1, "pass KV")):
-                t = s[:, :, 4 * mode:4 * mode + 4]
-                t = t[t[:, :, 3].sum(dim=1) > 0]  # workgroups that ran
+                t = s[:grid, :, 4 * mode:4 * mode + 4]
+                ran = t[:, :, 3].sum(dim=1) > 0
+                ph = s[grid:2 * grid, :, 4 * mode:4 * mode + 4][ran]  # compute, wait for rows, convert + store, barrier
+                tot = ph.sum(dim=(0, 1))
+                print(f"stage {stage + 1} C={c} {name}: tile loop = compute {float(tot[0] / tot.sum()) * 100:4.1f}%  wait for rows {float(tot[1] / tot.sum()) * 100:4.1f}%  "
+                      f"convert + LDS store {float(tot[2] / tot.sum()) * 100:4.1f}%  barrier {float(tot[3] / tot.sum()) * 100:4.1f}%")
+                t = t[ran]  # workgroups that ran
                 life = t[:, :, :3].sum(dim=2).max(dim=1).values  # longest wave of the workgroup, in 10 ns ticks
                 pro, loop, epi = (t[:, :, i].mean(dim=1) for i in range(3))
                 steps = t[:, 0, 3]
