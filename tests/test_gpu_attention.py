@@ -11,6 +11,9 @@ import refcfg
 pytestmark = pytest.mark.gpu
 
 WINDOW_SIZES = [1, 2, 15, 16, 17, 31, 32, 33, 64, 100, 129, 257, 300, 640]
+# windows whose LAST 32-token tile holds 16 / 17 tokens (the backward skips the tile's empty second half) and the 128-token
+# chunk edge with the same remainders
+HALF_TILE_SIZES = [48, 49, 80, 81, 144, 145, 176, 177]
 
 
 @pytest.fixture(scope="module")
@@ -18,13 +21,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(scope="module")
-def windows(dev):
-    """Voxel coordinates whose shift-0 windows hold exactly WINDOW_SIZES tokens, rows shuffled."""
+def _windows_of(dev, sizes):
     from openseg3d_amd.swformer import SparseWindowPartitionLayer
     rs = np.random.RandomState(0)
     rows = []
-    for i, n in enumerate(WINDOW_SIZES):
+    for i, n in enumerate(sizes):
         cells = rs.permutation(800)[:n]
         z, y, x = cells // 100, (cells // 10) % 10, cells % 10
         rows.append(np.stack([np.zeros(n), z + 8, y + 10 * (1 + i % 3), x + 10 * (1 + i)], axis=1))
@@ -34,8 +35,19 @@ def windows(dev):
     plan = part.plan(torch.from_numpy(coords).to(dev), 1, 48)
     wi = plan.index[0]
     counts = wi.win_count[: wi.n_windows].cpu().numpy()
-    assert sorted(counts.tolist()) == sorted(WINDOW_SIZES)
+    assert sorted(counts.tolist()) == sorted(sizes)
     return wi, coords.shape[0]
+
+
+@pytest.fixture(scope="module")
+def windows(dev):
+    """Voxel coordinates whose shift-0 windows hold exactly WINDOW_SIZES tokens, rows shuffled."""
+    return _windows_of(dev, WINDOW_SIZES)
+
+
+@pytest.fixture(scope="module")
+def half_tile_windows(dev):
+    return _windows_of(dev, HALF_TILE_SIZES)
 
 
 def reference(qk, v, tau, tau_min, heads, wi, keep=None):
@@ -101,6 +113,37 @@ def test_attention_forward_and_backward_vs_fp64(dev, windows, dh, tau):
 
 # ------------------------------------------------------------------------------------------ attention dropout
 from dropout_ref import dropout_factors  # noqa: E402  (csrc/attn_dropout.hpp restated with numpy)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("dh", [12, 24, 48])
+def test_half_empty_last_tiles(dev, half_tile_windows, dh, p):
+    """The fused backward skips the second 16-token half of a window's last streamed tile when it holds no token, and both
+    directions switch tokens past the window's end off inside the score product (spare K channel) or by their LSE: windows
+    whose last tile holds exactly 16 and 17 tokens, at the tile and at the 128-token chunk edge, with and without dropout."""
+    from openseg3d_amd import ops
+    wi, m = half_tile_windows
+    heads, c, seed = 8, 8 * dh, 0x0123_4567_89AB_CDEF
+    gen = torch.Generator().manual_seed(100 + dh)
+    qk = torch.randn(m, 2 * c, generator=gen, dtype=torch.float64)
+    v = torch.randn(m, c, generator=gen, dtype=torch.float64)
+    g = torch.randn(m, c, generator=gen, dtype=torch.float64)
+    tau_t = torch.full((1, 1, 1), 0.5, dtype=torch.float64)
+    keep = None
+    if p > 0:
+        counts = wi.win_count[: wi.n_windows].cpu().tolist()
+        keep = {(w, h): torch.from_numpy(dropout_factors(p, seed, w, h, n)) for w, n in enumerate(counts) for h in range(heads)}
+    qk_r, v_r, tau_r = qk.clone().requires_grad_(), v.clone().requires_grad_(), tau_t.clone().requires_grad_()
+    ref = reference(qk_r, v_r, tau_r, 0.01, heads, wi, keep)
+    ref.backward(g)
+    qk_g, v_g = qk.float().to(dev).requires_grad_(), v.float().to(dev).requires_grad_()
+    tau_g = tau_t.float().to(dev).requires_grad_()
+    out = ops.window_attention_packed(qk_g, v_g, tau_g, 0.01, heads, wi, p, seed)
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 3e-5 * float(v.abs().max())
+    out.backward(g.float().to(dev))
+    for got, want, name in ((v_g.grad, v_r.grad, "dv"), (qk_g.grad, qk_r.grad, "dqk"), (tau_g.grad, tau_r.grad, "dtau")):
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got.cpu().double() - want).abs().max()) < (2e-3 if name == "dtau" else 3e-4) * scale, name
 
 
 @pytest.mark.parametrize("dh", [6, 12, 24, 48])
