@@ -459,6 +459,12 @@ def test_bench_streams_and_pipeline_train_the_same_weights():
     b = run(["--no-pipeline"], {"SEG3D_WGRAD_STREAM": "0", "SEG3D_AUX_OVERLAP": "0"})
     assert "third stream" in a["config"]["streams"] and "--no-pipeline" in b["config"]["streams"]
     assert a["trained_weights_l1"] == b["trained_weights_l1"] and a["trained_weights_l1"] > 0
+    # the same steps as ONE rank of a data-parallel job (RCCL group of one, dist.SceneParallel: gradients packed into the
+    # arena, averaged over one rank, .grad rebound to arena views; the deferred join stays on): the same weights again
+    c = run([], {"SEG3D_BENCH_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": "29531"})
+    assert c["config"]["collective"].startswith("nccl world 1")
+    assert c["trained_weights_l1"] == a["trained_weights_l1"]
 
 
 def test_deferred_join_probe_passes_and_catches_a_broken_engine(monkeypatch):
