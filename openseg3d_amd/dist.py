@@ -137,6 +137,9 @@ class SceneParallel(torch.nn.Module):
         self._sync = True
         self._queued = False
         self._params = [p for p in module.parameters() if p.requires_grad]
+        if len({(p.dtype, p.device) for p in self._params}) > 1:  # one flat arena: one dtype, one device
+            raise ValueError("SceneParallel needs every trainable parameter on one device in one dtype; "
+                             "SEG3D_DDP=torch selects torch's DistributedDataParallel")
         if bucket_bytes is None:
             bucket_bytes = int(float(os.environ.get("SEG3D_DDP_BUCKET_MB", "32")) * (1 << 20))
         self._bucket = max(int(bucket_bytes) // 4, 1)
