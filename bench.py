@@ -634,21 +634,31 @@ def main():
         taus = [float(p.detach()) for n, p in model.named_parameters() if n.endswith(".tau")]
         if taus and out["attention_roofline"] is not None:
             out["attention_roofline"]["tau_range_after_steps"] = [round(min(taus), 4), round(max(taus), 4)]
-        if (train and world == 1 and not args.no_fp32_exact and _ops.CONV_PRECISION == "bf16x3" and args.workload == "one_sweep"
-                and args.segmentor == "segformer"):
+        profiled = any(k in os.environ for k in ("ROCPROFILER_SDK_TOOL_LIBRARIES", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) \
+            or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if (train and world == 1 and not distributed and not profiled and not args.no_fp32_exact
+                and _ops.CONV_PRECISION == "bf16x3" and args.workload == "one_sweep" and args.segmentor == "segformer"):
             # the same step with every conv / Linear product an exact fp32 MFMA (the reference's arithmetic), in a fresh child
             # process (the switch is read at import): the same-precision number, driver-recorded
             import subprocess
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--scenes", "2",
-                                    "--no-cpu-baseline", "--no-fp32-exact"], capture_output=True, text=True, timeout=600,
-                                   env=dict(os.environ, SEG3D_CONV_PRECISION="fp32"))
-            fp32 = {"error": child.stderr[-300:]}
-            for line in child.stdout.splitlines():
-                if line.startswith("{"):
-                    d = json.loads(line)
-                    fp32 = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "dtype": d["dtype"],
-                            "fwd_only_ms_per_step": d["fwd_only"]["ms_per_step"], "steps": d["steps"],
-                            "note": "SEG3D_CONV_PRECISION=fp32: v_mfma_f32_16x16x4_f32 products (1/16 of the bf16 MFMA rate)"}
+            # a fresh single-process child: no rendezvous variables of an outer launcher (torchrun with one rank would
+            # collide on the port), and never a second process under a profiler that wraps this one
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                                "MASTER_PORT", "TORCHELASTIC_RUN_ID", "SEG3D_BENCH_DIST")}
+            env["SEG3D_CONV_PRECISION"] = "fp32"
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--scenes", "2",
+                                        "--no-cpu-baseline", "--no-fp32-exact"], capture_output=True, text=True, timeout=600, env=env)
+                fp32 = {"error": child.stderr[-300:]}
+                for line in child.stdout.splitlines():
+                    if line.startswith("{"):
+                        d = json.loads(line)
+                        fp32 = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "dtype": d["dtype"],
+                                "fwd_only_ms_per_step": d["fwd_only"]["ms_per_step"], "steps": d["steps"],
+                                "note": "SEG3D_CONV_PRECISION=fp32: v_mfma_f32_16x16x4_f32 products (1/16 of the bf16 MFMA rate)"}
+            except (subprocess.SubprocessError, OSError, ValueError, KeyError, TypeError) as e:  # the record above must survive
+                fp32 = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["fp32_exact"] = fp32
         if baseline is not None:
             out["cpu_baseline"], out["parity"] = baseline

@@ -81,6 +81,23 @@ int seg3d_voxelize_f64(const double* points, int64_t n_points, int32_t row_strid
                        int32_t* voxel_coords, int32_t* point_voxel_ids, int32_t* n_voxels,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* (b) The CPU entry of VoxelGenerator.generate -- seg3d/core/voxel/voxel_generator.py:24-26 (-> points_to_voxel :55-95,
+ * _points_to_voxel_reverse_kernel :98-153), called by DataLoader workers (seg3d/datasets/waymo_dataset.py:275) and
+ * test-time augmentation (test_time_aug.py:33): forked processes WITHOUT a GPU context, which SURVEY 8(b) says must keep
+ * a CPU voxelizer.  Same contract as seg3d_voxelize_f32 / _f64 with every pointer a HOST pointer and no stream: the
+ * reference's serial first-seen loop, the dense 531 MB lookup grid replaced by an open-addressing table in the caller's
+ * workspace.  Plain host code: makes no HIP call (safe after fork, runs on a machine without a GPU).  n_voxels: host
+ * int32[1]; voxel_coords host [>= n_points, 4] rows (b, z, y, x). */
+size_t seg3d_voxelize_host_workspace_bytes(int64_t n_points);
+int seg3d_voxelize_host_f32(const float* points, int64_t n_points, int32_t row_stride, int32_t xyz_col,
+                            int32_t batch_col, const float* voxel_size, const float* range,
+                            int32_t* voxel_coords, int32_t* point_voxel_ids, int32_t* n_voxels,
+                            void* workspace, size_t workspace_bytes);
+int seg3d_voxelize_host_f64(const double* points, int64_t n_points, int32_t row_stride, int32_t xyz_col,
+                            int32_t batch_col, const float* voxel_size, const float* range,
+                            int32_t* voxel_coords, int32_t* point_voxel_ids, int32_t* n_voxels,
+                            void* workspace, size_t workspace_bytes);
+
 /* ------------------------------------------------------------------------------------------
  * a3  cart2polar -- seg3d/utils/pointops_utils.py:8-11, wired into the cylinder configs at
  *     seg3d/datasets/waymo_dataset.py:270-273: rows [.., x, y, z, f..] -> [.., rho, phi, z, x, y, f..]
@@ -201,7 +218,11 @@ int seg3d_spconv_fwd_presplit(const void* xs, const int32_t* nbr, int64_t m_out,
  * per (offset, row), the LDS slot of the neighbour's row.  seg3d_spconv_fwd_tiled then loads and splits every distinct
  * input row of a tile ONCE per 32-channel slice into an LDS image and feeds all 27 offsets from it (spconv_split gathers and
  * splits per (row, offset) pair: 6.5 - 17 times per row).  Results are bit-identical to seg3d_spconv_fwd_act on the same
- * operands (same products in the same order per output row).  coords [m_out, 4] (b, z, y, x) int32 are the sites the
+ * operands (same products in the same order per output row) for cout a multiple of 96 or 128.  EXCEPTION: cout 32 / 48
+ * (and therefore cin 32 / 48 of the input-gradient conv, whose cout is the forward's cin) run the offset-split layouts --
+ * the four waves of a workgroup take a quarter of a tile's 27 offsets each and their partial tiles are summed through LDS
+ * in a fixed order: deterministic run to run, but ANOTHER summation order than seg3d_spconv_fwd_act's ascending offsets,
+ * so the two entry points agree there to fp32 round-off (a few 1e-7 relative), not bit for bit.  coords [m_out, 4] (b, z, y, x) int32 are the sites the
  * table's rows belong to; nbr [27][m_out] may gather from any row set (m_in rows).  cout a multiple of 96 or 128, or 32 / 48
  * (seg3d_spconv_tiled_supported), split-bf16 packs only; forward and dgrad (W^T pack, flipped offsets) share one plan. */
 size_t seg3d_conv_plan_bytes(int64_t m_out);

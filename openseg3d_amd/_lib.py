@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
@@ -26,6 +26,9 @@ SIGNATURES = {
     "seg3d_voxelize_workspace_bytes": (_sz, [_i64]),
     "seg3d_voxelize_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "seg3d_voxelize_f64": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "seg3d_voxelize_host_workspace_bytes": (_sz, [_i64]),
+    "seg3d_voxelize_host_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz]),
+    "seg3d_voxelize_host_f64": (ctypes.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz]),
     "seg3d_cart2polar_f32": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "seg3d_cart2polar_f64": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "seg3d_group_index_workspace_bytes": (_sz, [_i64, _i64]),

@@ -53,11 +53,14 @@ class VoxelGenerator:
         points [N, >= 3] float32 / float64  ->  (coors int32 [M, 3] as (z, y, x) in first-seen order,
                                                   point_voxel_ids int32 [N], -1 = out of range)
 
-    with the subtract and the true divide done in the points' own dtype.  A numpy array goes to the GPU
-    and the result comes back as numpy (the call sites waymo_dataset.py:275 and test_time_aug.py:33 index it as numpy); a
-    CUDA tensor stays on the device and returns tensors (the fast path for TTA, whose 36 re-voxelizations per frame
-    then never leave the card).  There is no CPU implementation behind this class: the product path has no CPU fallback
-    by rule, so a DataLoader worker without a GPU context keeps the reference's numba voxelizer."""
+    with the subtract and the true divide done in the points' own dtype.  Two entries, as SURVEY 8(b)
+    asks: a NUMPY array is voxelized ON THE HOST by the library's own CPU entry (seg3d_voxelize_host_f32 / _f64: the
+    reference's serial first-seen loop over a hash instead of the 531 MB dense grid; no HIP call, so it runs in forked
+    DataLoader workers -- waymo_dataset.py:275 -- and test_time_aug.py:33 exactly where the reference's numba kernel ran)
+    and returns numpy; a CUDA tensor stays on the device (seg3d_voxelize_f32 / _f64) and returns tensors -- the fast path
+    of the bench and of a TTA loop whose 36 re-voxelizations per frame then never leave the card.  Both are product code
+    of libseg3d_hip.so; neither is a fallback for the other (a CUDA tensor is never sent to the host entry, a numpy
+    array never to the device)."""
 
     def __init__(self, voxel_size, point_cloud_range, device="cuda"):
         point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
@@ -70,15 +73,16 @@ class VoxelGenerator:
 
     def generate(self, points):
         """Generate voxels given points (voxel_generator.py:24-26, 55-95)."""
-        as_numpy = isinstance(points, np.ndarray)
-        pts = torch.from_numpy(np.ascontiguousarray(points)).to(self._device) if as_numpy else points
+        if isinstance(points, np.ndarray):
+            if points.ndim != 2 or points.shape[1] < 3:
+                raise ValueError("points must be [N, >= 3]")
+            coords, ids = ops.voxelize_host(points, self._voxel_size.tolist(), self._point_cloud_range.tolist())
+            return np.ascontiguousarray(coords[:, 1:]), ids
+        pts = points
         if pts.dim() != 2 or pts.shape[1] < 3:
             raise ValueError("points must be [N, >= 3]")
         coords, ids = ops.voxelize(pts, self._voxel_size.tolist(), self._point_cloud_range.tolist())
-        coors = coords[:, 1:].contiguous()  # the device voxelizer carries a batch column: (b, z, y, x) -> (z, y, x)
-        if as_numpy:
-            return coors.cpu().numpy(), ids.cpu().numpy()
-        return coors, ids
+        return coords[:, 1:].contiguous(), ids  # the device voxelizer carries a batch column: (b, z, y, x) -> (z, y, x)
 
     @property
     def voxel_size(self):

@@ -30,6 +30,12 @@
 
 #include "common.hpp"
 
+#ifdef SEG3D_TILE_DBG
+#define TILE_DBG(d) (d)
+#else
+#define TILE_DBG(d) 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -355,17 +361,17 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const void* __
     // fragments from register set S
     auto multiply = [&](auto S, uint32_t bmw, const uint32_t* li /* RB image slots of this lane's rows */) {
         if (bmw == 0u) return;
-        if (dbg & 8) bmw = (1u << RB) - 1u;
+        if (TILE_DBG(dbg) & 8) bmw = (1u << RB) - 1u;
         bf16x8 a_hi[2], a_lo[2];
         {
-            const uint32_t s = (dbg & 4) ? (uint32_t)lane : li[0] ^ (uint32_t)g;
+            const uint32_t s = (TILE_DBG(dbg) & 4) ? (uint32_t)lane : li[0] ^ (uint32_t)g;
             a_hi[0] = __builtin_bit_cast(bf16x8, img[s]);
             if constexpr (IO != 2) a_lo[0] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (rb + 1 < RB) {
-                const uint32_t s = (dbg & 4) ? (uint32_t)(lane + 8 * rb) : li[rb + 1] ^ (uint32_t)g;
+                const uint32_t s = (TILE_DBG(dbg) & 4) ? (uint32_t)(lane + 8 * rb) : li[rb + 1] ^ (uint32_t)g;
                 a_hi[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s]);
                 if constexpr (IO != 2) a_lo[(rb + 1) & 1] = __builtin_bit_cast(bf16x8, img[s ^ 4u]);
             }
@@ -458,14 +464,14 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const void* __
         // multiply the current one.  The next chunk's loads are issued unconditionally (past the end: the last chunk again)
         // so that the count of loads in flight is the same on every path and the compiler waits for exactly the current set.
         auto run = [&](auto SC, auto SN, const Chunk& cur, Chunk& nxt) {
-            if (cur.first && !((dbg & 1) && cur.cb > 0)) {  // new 32-channel slice: every wave is done with the old image, refill it
+            if (cur.first && !((TILE_DBG(dbg) & 1) && cur.cb > 0)) {  // new 32-channel slice: every wave is done with the old image, refill it
                 __syncthreads();
                 stage(cur.cb, U, [&](int u) { return uniq_s[u]; });
                 __syncthreads();
             }
             nxt = next_chunk();
             const int kn = nxt.have ? nxt.k : cur.k, cbn = nxt.have ? nxt.cb : cur.cb;
-            if (!(dbg & 2)) load_b(SN, kn, cbn);
+            if (!(TILE_DBG(dbg) & 2)) load_b(SN, kn, cbn);
             slots_of(kn, li[SN]);
             bmw[SN] = block_mask(kn);
             multiply(SC, bmw[SC], li[SC]);
@@ -573,16 +579,23 @@ __global__ __launch_bounds__(kThreads, 2) void spconv_tile_kernel(const void* __
 }
 
 // timing experiments only (SEG3D_TILE_DBG bit mask, results become WRONG): 1 = image staged for the first slice only,
-// 2 = B fragments never reloaded, 4 = A fragments read from fixed conflict-free slots, 8 = no block skipping
+// 2 = B fragments never reloaded, 4 = A fragments read from fixed conflict-free slots, 8 = no block skipping.  Compiled in
+// only by a -DSEG3D_TILE_DBG build (tools/r4_tile_dbg.sh); the shipped library ignores the variable and its kernels carry
+// no trace of the experiments (TILE_DBG(x) is the constant 0).
+#ifdef SEG3D_TILE_DBG
 static const int g_tile_dbg = [] {
     const char* e = getenv("SEG3D_TILE_DBG");
     return e ? atoi(e) : 0;
 }();
+#else
+static const int g_tile_dbg = 0;
+#endif
 
-// SEG3D_TILE_RUN (A/B): consecutive tiles per XCD run (0 = automatic)
+// SEG3D_TILE_RUN (A/B): consecutive tiles per XCD run (0 or anything outside 1..64 = automatic)
 static const int g_tile_run = [] {
     const char* e = getenv("SEG3D_TILE_RUN");
-    return e ? atoi(e) : 0;
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= 64) ? v : 0;
 }();
 
 template <int WR, int WC, int NBW, bool KS = false>
@@ -631,7 +644,8 @@ static int tile_layout(int cin, int cout) {
 // SEG3D_TILE_LAYOUT (A/B): force a layout id where it divides cout
 static const int g_tile_layout = [] {
     const char* e = getenv("SEG3D_TILE_LAYOUT");
-    return e ? atoi(e) : 0;
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= 5) ? v : 0;  // anything else: automatic
 }();
 
 int spconv_tile_fwd(const void* x, const int32_t* nbr, const void* plan, int64_t m_out, const void* wp, const float* bias,

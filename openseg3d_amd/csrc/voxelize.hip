@@ -209,6 +209,82 @@ int cart2polar_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_
     return SEG3D_OK;
 }
 
+
+// (b) the CPU entry of VoxelGenerator.generate (voxel_generator.py:24-26 -> points_to_voxel :55-95 ->
+// _points_to_voxel_reverse_kernel :98-153), for DataLoader workers and TTA, which run without a GPU context.  The same
+// serial loop as the reference -- first-seen order falls out of it -- with the dense coor_to_voxelidx grid (531 MB of page
+// faults per call at 1440 x 1440 x 64) replaced by an open-addressing table over the linear cell index in the caller's
+// workspace (12 bytes per slot, >= 2 slots per point).  Plain host C++: no HIP call, safe in a forked worker.
+inline float floor_h(float v) { return __builtin_floorf(v); }
+inline double floor_h(double v) { return __builtin_floor(v); }
+
+inline uint64_t host_capacity(int64_t n) {
+    uint64_t cap = 64;
+    while (cap < (uint64_t)(2 * n + 2)) cap <<= 1;
+    return cap;
+}
+
+template <typename T>
+int voxelize_host_impl(const T* points, int64_t n, int32_t row_stride, int32_t xyz_col, int32_t batch_col,
+                       const float* voxel_size, const float* range, int32_t* voxel_coords, int32_t* point_voxel_ids,
+                       int32_t* n_voxels, void* workspace, size_t workspace_bytes) {
+    if (n < 0 || n >= (int64_t)0x7F000000 || !voxel_size || !range || !n_voxels || row_stride < 3 || xyz_col < 0 ||
+        xyz_col + 3 > row_stride || batch_col >= row_stride)
+        return SEG3D_EINVAL;
+    if (n > 0 && (!points || !point_voxel_ids || !voxel_coords || !workspace)) return SEG3D_EINVAL;
+    const uint64_t cap = host_capacity(n);
+    if (n > 0 && workspace_bytes < cap * 12) return SEG3D_EWORKSPACE;
+    int32_t grid[3];
+    if (seg3d_grid_size(voxel_size, range, grid) != SEG3D_OK) return SEG3D_EINVAL;
+    *n_voxels = 0;
+    if (n == 0) return SEG3D_OK;
+    uint64_t* keys = static_cast<uint64_t*>(workspace);
+    int32_t* vals = reinterpret_cast<int32_t*>(keys + cap);
+    for (uint64_t s = 0; s < cap; ++s) keys[s] = ~0ull;
+    // volatile: the subtract and the divide are two IEEE operations in the point dtype (no contraction, no reassociation
+    // whatever flags a host compiler is given), float32 constants widened exactly for the f64 entry
+    T lo[3], vs[3];
+    for (int j = 0; j < 3; ++j) {
+        lo[j] = (T)range[j];
+        vs[j] = (T)voxel_size[j];
+    }
+    int32_t count = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const T* row = points + i * row_stride;
+        int32_t cc[3];
+        bool ok = true;
+        for (int j = 0; j < 3 && ok; ++j) {
+            volatile T d = row[xyz_col + j] - lo[j];
+            volatile T q = d / vs[j];
+            const T v = floor_h((T)q);  // voxel_generator.py:139
+            if (!(v >= (T)0) || v >= (T)grid[j]) ok = false;  // (a NaN coordinate fails both of the reference's tests and
+            else cc[j] = (int32_t)v;                           //  would index the grid with garbage there: rejected here)
+        }
+        if (!ok) {
+            point_voxel_ids[i] = -1;
+            continue;
+        }
+        const int64_t b = batch_col >= 0 ? (int64_t)row[batch_col] : 0;
+        const uint64_t key = (uint64_t)(((b * grid[2] + cc[2]) * grid[1] + cc[1]) * (int64_t)grid[0] + cc[0]);
+        uint64_t h = key * 0x9E3779B97F4A7C15ull;
+        uint64_t s = (h ^ (h >> 29)) & (cap - 1);
+        while (keys[s] != key && keys[s] != ~0ull) s = (s + 1) & (cap - 1);
+        if (keys[s] == ~0ull) {
+            keys[s] = key;
+            vals[s] = count;
+            int32_t* o = voxel_coords + 4 * (int64_t)count;
+            o[0] = (int32_t)b;
+            o[1] = cc[2];
+            o[2] = cc[1];
+            o[3] = cc[0];
+            ++count;
+        }
+        point_voxel_ids[i] = vals[s];
+    }
+    *n_voxels = count;
+    return SEG3D_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -222,7 +298,7 @@ int seg3d_cart2polar_f64(const double* points, int64_t n_points, int32_t row_str
     return cart2polar_impl<double>(points, n_points, row_stride, xyz_col, out, stream);
 }
 
-int seg3d_abi_version(void) { return 34; }
+int seg3d_abi_version(void) { return 35; }
 
 namespace {
 thread_local char g_last_error[320] = "";
@@ -256,6 +332,22 @@ int seg3d_voxelize_f64(const double* points, int64_t n_points, int32_t row_strid
                        int32_t* n_voxels, void* workspace, size_t workspace_bytes, void* stream) {
     return voxelize_impl<double>(points, n_points, row_stride, xyz_col, batch_col, voxel_size, range, voxel_coords,
                                  point_voxel_ids, n_voxels, workspace, workspace_bytes, stream);
+}
+
+size_t seg3d_voxelize_host_workspace_bytes(int64_t n_points) { return (size_t)host_capacity(n_points < 0 ? 0 : n_points) * 12; }
+
+int seg3d_voxelize_host_f32(const float* points, int64_t n_points, int32_t row_stride, int32_t xyz_col, int32_t batch_col,
+                            const float* voxel_size, const float* range, int32_t* voxel_coords, int32_t* point_voxel_ids,
+                            int32_t* n_voxels, void* workspace, size_t workspace_bytes) {
+    return voxelize_host_impl<float>(points, n_points, row_stride, xyz_col, batch_col, voxel_size, range, voxel_coords,
+                                     point_voxel_ids, n_voxels, workspace, workspace_bytes);
+}
+
+int seg3d_voxelize_host_f64(const double* points, int64_t n_points, int32_t row_stride, int32_t xyz_col, int32_t batch_col,
+                            const float* voxel_size, const float* range, int32_t* voxel_coords, int32_t* point_voxel_ids,
+                            int32_t* n_voxels, void* workspace, size_t workspace_bytes) {
+    return voxelize_host_impl<double>(points, n_points, row_stride, xyz_col, batch_col, voxel_size, range, voxel_coords,
+                                      point_voxel_ids, n_voxels, workspace, workspace_bytes);
 }
 
 }  // extern "C"

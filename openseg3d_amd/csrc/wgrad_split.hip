@@ -46,7 +46,8 @@ Plan plan(int64_t m, int cin, int cout) {
     // rows; at least ~1000 workgroups per launch
     static const int rows_target = [] {
         const char* e = getenv("SEG3D_WGRAD_SPARSE_ROWS");
-        return e ? atoi(e) : 3072;
+        const int v = e ? atoi(e) : 3072;
+        return v >= 64 ? v : 3072;  // 0 / non-numeric / tiny values: the default (never a division by zero)
     }();
     int64_t chunks = m / rows_target;
     const int64_t need = (1024 + 27 * tiles - 1) / (27 * tiles);

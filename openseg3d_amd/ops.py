@@ -150,7 +150,7 @@ WGRAD_DEFER = os.environ.get("SEG3D_WGRAD_DEFER", "1") != "0"
 _DEFERRED = {}
 _DEFER_PROBE = {"done": False, "ok": None}
 _MAX_IDLE_STATES = 4  # records of other graph tasks tolerated beside the current one (see _state_for)
-DEFER_COUNT = 0       # joins deferred so far in this process (tests: a process with a process group must stay at 0)
+DEFER_COUNT = 0       # joins deferred so far in this process (tests: a process whose group belongs to plain DDP must stay at 0)
 
 
 def _graph_task_id():
@@ -164,7 +164,7 @@ def _state_key(device):
 
 def _new_state(task, device):
     return {"keep": [], "main": None, "side": None, "seen": set(), "twice": set(), "fix": [], "task": task, "jobs": [],
-            "jobs_device": device}
+            "jobs_device": device, "alias": {}}
 
 
 def _reset_deferred():
@@ -246,15 +246,68 @@ def _run_reduce_jobs(jobs, device, stream):
         _lib.call("seg3d_reduce_partials_batched", _ptr(table), len(jobs), first, sp)
 
 
-# Set by dist.SceneParallel: the process's gradients are exchanged by a wrapper that reads them only AFTER the backward
-# pass (no hooks on the AccumulateGrad nodes), so deferral is safe although a process group exists.  Anything else that
-# owns a process group (torch DDP built directly, FSDP, comm hooks) leaves it False.
-DEFER_WITH_GROUP = False
+# Parameters owned by a live dist.SceneParallel: that wrapper reads a gradient only behind its kernel on the side stream or
+# after the backward pass (its post-accumulate hooks are marked, see _foreign_hooks), so deferral is safe for THESE
+# parameters although a process group exists.  Anything else that owns a process group (torch DDP built directly, FSDP, comm
+# hooks) is not in the set and keeps the by-construction rule -- also when it is built later in the same process.
+class _IdentitySet:
+    """Weak set of tensors by IDENTITY (a WeakSet would compare members with ==, which is elementwise on tensors)."""
+
+    def __init__(self):
+        self._refs = {}
+
+    def add(self, t):
+        key = id(t)
+        self._refs[key] = weakref.ref(t, lambda _r, key=key, refs=self._refs: refs.pop(key, None))
+
+    def discard(self, t):
+        r = self._refs.get(id(t))
+        if r is not None and r() is t:
+            del self._refs[id(t)]
+
+    def __contains__(self, t):
+        r = self._refs.get(id(t))
+        return r is not None and r() is t
+
+    def __len__(self):
+        return len(self._refs)
+
+
+DEFER_OWNED = _IdentitySet()
 
 
 def _process_group_exists():
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and not DEFER_WITH_GROUP
+    return dist.is_available() and dist.is_initialized()
+
+
+def _foreign_hooks(base):
+    """True if the parameter carries a post-accumulate hook that is not SceneParallel's arrival counter."""
+    hooks = getattr(base, "_post_accumulate_grad_hooks", None)
+    return bool(hooks) and not all(getattr(h, "_seg3d_scene_parallel", False) for h in hooks.values())
+
+
+def deferred_alias(w):
+    """The buffer a pending deferred weight gradient of parameter `w` is being written to on the side stream (None if
+    nothing is pending for it): what a reader on the SIDE stream may consume before the pass ends."""
+    for st in _DEFERRED.values():
+        alias = st["alias"].get(id(w))
+        if alias is not None:
+            return alias
+    return None
+
+
+def flush_deferred_jobs(device):
+    """Run the fixed-order sums queued so far by the device's pending records NOW, on the side stream (behind every producer
+    enqueued on either stream): the gradients handed to autograd so far are then complete in side-stream order.  The
+    streams are not joined; the partial blocks stay referenced until the record completes."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    for key, st in list(_DEFERRED.items()):
+        if key[1] == dev and st["side"] is not None and st["jobs"]:
+            st["side"].wait_stream(st["main"])
+            _run_reduce_jobs(st["jobs"], st["jobs_device"], st["side"])
+            st["keep"].append(st["jobs"])
+            st["jobs"] = []
 
 
 def finish_deferred(device):
@@ -266,16 +319,18 @@ def finish_deferred(device):
 
 
 def _defer_join(fk, grads):
-    if torch.is_grad_enabled() or not grads or _DEFER_PROBE["ok"] is False or _process_group_exists():
+    if torch.is_grad_enabled() or not grads or _DEFER_PROBE["ok"] is False:
         return False
     st = _DEFERRED.get(_state_key(fk.device))  # (made below, only once something is really deferred)
     bases = [w if w._base is None else w._base for w, _ in grads]
+    if _process_group_exists() and not all(base in DEFER_OWNED for base in bases):
+        return False
     if st is not None and any(base.data_ptr() in st["seen"] for base in bases):
         st["twice"].update(base.data_ptr() for base in bases)  # second use: this call joins now, the engine sums
         return False
     for base in bases:
         if (not base.is_leaf or base.grad is not None or base._backward_hooks or not base.is_contiguous()
-                or getattr(base, "_post_accumulate_grad_hooks", None)):
+                or _foreign_hooks(base)):
             return False
     if st is None:  # first deferral of this graph task: its final callback completes the record
         key, st = _state_for(fk)
@@ -288,6 +343,7 @@ def _defer_join(fk, grads):
         st["seen"].add(base.data_ptr())
         if w is base:
             st["fix"].append((base, gr.detach()))
+            st["alias"][id(base)] = st["fix"][-1][1]
         else:
             st["keep"].append(gr.detach())  # gradient of a view of the parameter: autograd scatters it, no .grad to check
     global DEFER_COUNT
@@ -312,7 +368,7 @@ def probe_deferred_join(device):
     if pr["done"] or not (WGRAD_STREAM and WGRAD_DEFER) or device.type != "cuda":
         return pr["ok"]
     pr["done"] = True
-    if _process_group_exists():  # never deferred in such a process anyway
+    if _process_group_exists() and not len(DEFER_OWNED):  # never deferred in such a process anyway
         return None
     before = WGRAD_DEFER
     try:
@@ -328,6 +384,9 @@ def probe_deferred_join(device):
                 global WGRAD_DEFER
                 ws = [t.clone().requires_grad_() for t in w0]
                 bs = [t.clone().requires_grad_() for t in b0]
+                if _process_group_exists():  # a dist.SceneParallel owns this process's deferral: probe under its rule
+                    for t in ws + bs:
+                        DEFER_OWNED.add(t)
                 WGRAD_DEFER = defer
                 try:
                     if defer:
@@ -414,6 +473,31 @@ def voxelize(points, voxel_size, point_cloud_range, xyz_col=0, batch_col=-1):
     return coords[:m], ids
 
 
+def voxelize_host(points, voxel_size, point_cloud_range, xyz_col=0, batch_col=-1):
+    """The CPU entry of the voxelizer (seg3d_voxelize_host_f32 / _f64; include/seg3d_hip.h): what VoxelGenerator.generate
+    does in a DataLoader worker or in test-time augmentation, where there is no GPU context (voxel_generator.py:24-26,
+    waymo_dataset.py:275, test_time_aug.py:33).  points: float32 / float64 numpy [N, D].  Returns numpy
+    (voxel_coords int32 [M, 4] as (b, z, y, x) in first-seen order, point_voxel_ids int32 [N], -1 = out of range).
+    Host code of the same library; it makes no HIP call."""
+    import numpy as np
+    pts = np.ascontiguousarray(points)
+    if pts.ndim != 2 or pts.dtype not in (np.float32, np.float64):
+        raise _lib.Seg3dError("points must be a float32/float64 [N, D] array")
+    n, d = pts.shape
+    coords = np.empty((max(n, 1), 4), dtype=np.int32)
+    ids = np.empty((n,), dtype=np.int32)
+    count = np.zeros((1,), dtype=np.int32)
+    ws = np.empty((max(int(_lib.query("seg3d_voxelize_host_workspace_bytes", n)), 8),), dtype=np.uint8)
+
+    def host(a):
+        return ctypes.c_void_p(a.ctypes.data)
+
+    fn = "seg3d_voxelize_host_f32" if pts.dtype == np.float32 else "seg3d_voxelize_host_f64"
+    _lib.call(fn, host(pts), n, d, int(xyz_col), int(batch_col), _F3(*[float(v) for v in voxel_size]),
+              _F6(*[float(v) for v in point_cloud_range]), host(coords), host(ids), host(count), host(ws), ws.size)
+    return coords[: int(count[0])], ids
+
+
 def cart2polar(points, xyz_col=0):
     """``cart2polar`` + the row re-assembly of the cylinder configs (pointops_utils.py:8-11, waymo_dataset.py:270-273)
     on the device: float32/float64 [N, D] rows [.., x, y, z, f..] -> [N, D + 2] rows [.., rho, phi, z, x, y, f..]."""
@@ -484,6 +568,8 @@ def rulebook_subm(h):
 
 
 # a9 "row image" schedule of the submanifold convs (csrc/spconv_tile.hip): 0 = off, 1 = every layer the schedule takes.
+# (Bit-identical to the per-pair gather except in the 32 / 48-channel layers, whose offset-split layouts sum in another
+# fixed order: the switch moves those layers' results by fp32 round-off.)
 # SEG3D_CONV_TILED_MIN_C: smallest max(cin, cout) that takes it (narrower layers keep the per-pair gather).
 CONV_TILED = os.environ.get("SEG3D_CONV_TILED", "1") != "0"
 CONV_TILED_MIN_C = int(os.environ.get("SEG3D_CONV_TILED_MIN_C", "0"))
@@ -857,7 +943,10 @@ class _SparseConvFn(torch.autograd.Function):
 def sparse_conv(x, weight, bias, nbr, nbr_t, t_flags, packed=None, order=None, order_t=None, plan=None, plan_t=None):
     """order / order_t: optional processing orders (int32 permutations) of the rows of nbr / nbr_t -- see
     SiteLevel.parity_order; plan / plan_t: optional tile plans (ConvPlan) of nbr / nbr_t -- see SiteLevel.subm_plan.
-    They change scheduling only, never results."""
+    Orders change scheduling only, never results.  Plans likewise for cout (forward) / cin (input gradient) that are
+    multiples of 96 or 128; at 32 / 48 channels the tiled kernel splits a tile's 27 offsets over its four waves and sums
+    the partial tiles in a fixed order of its own -- deterministic, but SEG3D_CONV_TILED=0 and =1 then differ by fp32
+    round-off in those layers (include/seg3d_hip.h, seg3d_spconv_fwd_tiled)."""
     _need_gpu(x, weight, nbr)
     return _SparseConvFn.apply(x, weight, bias, nbr, nbr_t, t_flags, packed, order, order_t, plan, plan_t)
 

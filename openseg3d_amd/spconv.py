@@ -82,7 +82,8 @@ class SiteLevel:
     def subm_plan(self):
         """Tile plan of the submanifold table (ops.ConvPlan; None when the tiled schedule is switched off): Morton-ordered
         128-row tiles, their distinct input rows and image slots.  Built once, shared by every SubMConv3d on this level,
-        forward and input gradient (the transposed table is the same table with the offsets mirrored)."""
+        forward and input gradient (the transposed table is the same table with the offsets mirrored).  A plan changes the
+        schedule, and for 32 / 48-channel outputs also the (fixed) summation order: see ops.sparse_conv."""
         if not ops.CONV_TILED or ops.CONV_PRECISION != "bf16x3" or self.coords.shape[0] == 0:
             return None
         if self._subm_plan is None:

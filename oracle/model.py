@@ -234,10 +234,12 @@ def spnet_forward(batch, params, cfg):
     aux = F.linear(feats[3], p[pre + "aux_voxel_classifier.0.weight"])
     x4 = _ocr(feats[3], lvl[3], aux, int(batch["batch_size"]), p, pre + "ocr.")
 
-    x = _up_block(x4, x4, lvl[3].subm(), lvl[2].down()[2], p, pre + "up4.")
-    x = _up_block(x, feats[2], lvl[2].subm(), lvl[1].down()[2], p, pre + "up3.")
-    x = _up_block(x, feats[1], lvl[1].subm(), lvl[0].down()[2], p, pre + "up2.")
-    x = _up_block(x, feats[0], lvl[0].subm(), lvl[0].subm(), p, pre + "up1.")
+    taps = OrderedDict((f"conv{k + 1}", f) for k, f in enumerate(feats))  # per-stage outputs (tools/spnet_parity_probe.py)
+    taps["ocr"] = x4
+    x = taps["up4"] = _up_block(x4, x4, lvl[3].subm(), lvl[2].down()[2], p, pre + "up4.")
+    x = taps["up3"] = _up_block(x, feats[2], lvl[2].subm(), lvl[1].down()[2], p, pre + "up3.")
+    x = taps["up2"] = _up_block(x, feats[1], lvl[1].subm(), lvl[0].down()[2], p, pre + "up2.")
+    x = taps["up1"] = _up_block(x, feats[0], lvl[0].subm(), lvl[0].subm(), p, pre + "up1.")
     voxel_out = F.linear(x, p[pre + "voxel_classifier.0.weight"])
 
     res = OrderedDict()
@@ -249,4 +251,5 @@ def spnet_forward(batch, params, cfg):
     res["_levels"] = lvl
     res["_stage_feats"] = feats
     res["_voxel_in"] = vox
+    res["_taps"] = taps
     return res

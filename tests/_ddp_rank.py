@@ -36,17 +36,22 @@ def main():
     pts = scene.make_small_scene(20 + seed, 5000 + 1500 * seed, extent=8.0 + seed)
     b = B.make_batch([pts], ds.voxel_size, ds.point_cloud_range, device=dev)
     labels = torch.arange(b["points"].shape[0], device=dev) % 22
-    torch.manual_seed(5)  # DropPath / dropout seeds equal on every rank and in the reference runs
-    res = ddp(b)
-    loss = torch.nn.functional.cross_entropy(res["point_out"], labels) + res["voxel_out"].square().mean() \
-        + 0.4 * res["aux_voxel_out"].square().mean()
-    loss.backward()
+    # SEG3D_DDP_PASSES=2: the same step twice (gradients dropped in between) -- SceneParallel learns the arrival order in its
+    # first synchronised pass and exchanges slice by slice from the weight-gradient stream DURING the second
+    for _ in range(int(os.environ.get("SEG3D_DDP_PASSES", "1"))):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(5)  # DropPath / dropout seeds equal on every rank, in every pass and in the reference runs
+        res = ddp(b)
+        loss = torch.nn.functional.cross_entropy(res["point_out"], labels) + res["voxel_out"].square().mean() \
+            + 0.4 * res["aux_voxel_out"].square().mean()
+        loss.backward()
     torch.cuda.synchronize(dev)
     fp = {k: float(p.grad.double().abs().sum()) for k, p in model.named_parameters()}
     probe = model.point_transformer.swformer_block3[1].layers[0].mlp.fc1.weight.grad
     out = {"rank": rank, "world": world, "backend": dist.get_backend(), "total": float(sum(fp.values())),
            "n_nonfinite": int(sum(1 for v in fp.values() if v != v)), "probe": probe.double().flatten()[:64].tolist(),
-           "deferred_in_this_process": bool(ops._DEFERRED) or ops.DEFER_COUNT > 0}
+           "deferred_in_this_process": bool(ops._DEFERRED) or ops.DEFER_COUNT > 0,
+           "early_slices": getattr(ddp, "early_slices", None), "slices": len(getattr(ddp, "_slices", None) or [])}
     sys.stdout.write("\nDDPRANK " + json.dumps(out) + "\n")  # one write: the ranks share the pipe
     sys.stdout.flush()
     dist.barrier()

@@ -62,3 +62,50 @@ def test_host_only_entry_points():
     # argument validation happens before anything is enqueued: a null call is rejected, not launched
     assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 0, None, 48, 48, None, None, None) == _lib.EINVAL
     assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 4, None, 50, 48, None, None, None) == _lib.EINVAL
+
+
+@pytest.mark.parametrize("tag,rng,vs", [("cart", [-72, -72, -2, 72, 72, 4.4], [0.1, 0.1, 0.1]),
+                                        ("cyl", [0, -3.1415926, -2, 75.2, 3.1415926, 5.2], [0.05, 0.012, 0.1])])
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_host_voxelizer_bit_exact_vs_reference(tag, rng, vs, dt):
+    """VoxelGenerator.generate runs in DataLoader workers and TTA without a GPU context, so the CPU entry
+    "must stay".  The library's own host entry (seg3d_voxelize_host_f32 / _f64, plain C++ in libseg3d_hip.so, no import of
+    oracle/) against the outputs of the reference's points_to_voxel (tests/golden/voxelize.npz): coordinates in first-seen
+    order and point -> voxel ids bit for bit, float32 and float64 rows, cartesian and cylinder grids."""
+    import numpy as np
+    from openseg3d_amd import batch, ops
+    d = np.load(os.path.join(ROOT, "tests", "golden", "voxelize.npz"))
+    k = f"{tag}_{dt}"
+    pts = d[k + "_points"]
+    gen = batch.VoxelGenerator(vs, rng)
+    coors, ids = gen.generate(pts)  # numpy in -> the host entry, numpy out (voxel_generator.py:24-26)
+    assert isinstance(coors, np.ndarray) and coors.dtype == np.int32 and ids.dtype == np.int32
+    assert np.array_equal(coors, d[k + "_coors"]) and np.array_equal(ids, d[k + "_ids"])
+    assert gen.grid_size.tolist() == d[tag + "_grid"].tolist()
+    # collated form: a batch column in front, the same sample twice -> the second copy's voxels are new rows of batch 1
+    rows = np.concatenate([np.pad(pts, ((0, 0), (1, 0)), constant_values=b) for b in (0.0, 1.0)])
+    c4, i2 = ops.voxelize_host(rows, vs, rng, xyz_col=1, batch_col=0)
+    m, n = coors.shape[0], pts.shape[0]
+    assert np.array_equal(c4[:m, 1:], coors) and (c4[:m, 0] == 0).all() and np.array_equal(c4[m:, 1:], coors) and (c4[m:, 0] == 1).all()
+    assert np.array_equal(i2[:n], ids) and np.array_equal(i2[n:], np.where(ids >= 0, ids + m, -1))
+
+
+def test_host_voxelizer_edge_cases():
+    import numpy as np
+    from openseg3d_amd import _lib, ops
+    vs, rng = [0.1, 0.1, 0.1], [-72, -72, -2, 72, 72, 4.4]
+    c, i = ops.voxelize_host(np.zeros((0, 6), np.float32), vs, rng)
+    assert c.shape == (0, 4) and i.shape == (0,)
+    p = np.array([[0, 0, 0, 0, 0, 0], [1e6, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [0.05, 0.05, 0.05, 0, 0, 0],
+                  [np.nan, 0, 0, 0, 0, 0], [72.0, 0, 0, 0, 0, 0], [-72.0, -72.0, -2.0, 0, 0, 0]], np.float32)
+    c, i = ops.voxelize_host(p, vs, rng)
+    assert i.tolist() == [0, -1, 0, 0, -1, -1, 1] and c.tolist() == [[0, 20, 720, 720], [0, 0, 0, 0]]
+    with pytest.raises(_lib.Seg3dError):
+        ops.voxelize_host(np.zeros((4, 6), np.int32), vs, rng)
+    with pytest.raises(_lib.Seg3dError):  # a workspace that is too small is refused, not overrun
+        ws = np.empty((64,), np.uint8)
+        cnt = np.zeros((1,), np.int32)
+        out_c, out_i = np.empty((7, 4), np.int32), np.empty((7,), np.int32)
+        F3, F6 = ctypes.c_float * 3, ctypes.c_float * 6
+        _lib.call("seg3d_voxelize_host_f32", p.ctypes.data, 7, 6, 0, -1, F3(*vs), F6(*rng), out_c.ctypes.data, out_i.ctypes.data,
+                  cnt.ctypes.data, ws.ctypes.data, ws.size)

@@ -28,6 +28,7 @@ def _worker(rank, world, port, out):
     dist.all_gather_object(gathered, seeds)
     assert sorted(sum(gathered, [])) == list(range(3 * world))
     from openseg3d_amd import config, segformer  # noqa: F401  (the package imports on a CPU-only rank)
+    from openseg3d_amd import ops as ops_mod
     # the wrapper bench.py trains through (tools/train.py:246-247, 276-279): DistributedDataParallel over this process group;
     # after backward every rank holds the mean of the ranks' gradients
     torch.manual_seed(7)
@@ -60,7 +61,7 @@ def _worker(rank, world, port, out):
 
         def forward(self, x):
             y = self.body(x)
-            return {"a": y, "b": y.detach(), "n": x.shape[0]}
+            return {"a": y, "b": y.detach(), "n": x.shape[0], "deep": {"list": [y * 2.0, "text"]}}
 
     torch.manual_seed(100 + rank)
     net = Net()
@@ -76,7 +77,9 @@ def _worker(rank, world, port, out):
     res = sp(xs[rank])
     assert res["n"] == xs[rank].shape[0] and not res["b"].requires_grad
     res["a"].square().mean().backward()
-    assert sp.exchanges == 1
+    # the first synchronised pass exchanges after the pass and LEARNS the order in which gradients arrive (rank 0's)
+    assert sp.exchanges == 1 and sp.early_slices == 0 and sp._learned
+    assert sp._params[sp._order[-1]] is net.unused  # never fires: last in the arena, its slice closes in the final callback
     want = [torch.zeros_like(p) for p in twin2.body.parameters()]
     for r in range(world):
         twin2.zero_grad()
@@ -96,8 +99,47 @@ def _worker(rank, world, port, out):
         assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-8)  # local gradient, nothing exchanged
     sp(xs[rank])["a"].square().mean().backward()  # accumulates onto the local gradient, then exchanges the sum
     assert sp.exchanges == 2
+    # ... slice by slice DURING the pass this time: the arena follows the arrival order, and every slice whose gradients
+    # (and those of the slices in front of it) had arrived was exchanged from its post-accumulate hook
+    assert len(sp._slices) >= 4 and 0 < sp.early_slices < len(sp._slices)
     for p, ref_g in zip(net.body.parameters(), want):
         assert torch.allclose(p.grad, 2 * ref_g, rtol=1e-5, atol=1e-7)
+    assert float(net.unused.grad.abs().sum()) == 0.0
+    # a loss built from a tensor nested two containers deep still ends in an exchange (one level only before)
+    sp.zero_grad(set_to_none=True)
+    early = sp.early_slices
+    nested = sp(xs[rank])
+    assert nested["deep"]["list"][1] == "text"
+    nested["deep"]["list"][0].square().mean().backward()
+    assert sp.exchanges == 3 and sp.early_slices > early
+    for p, ref_g in zip(net.body.parameters(), want):
+        assert torch.allclose(p.grad, 4 * ref_g, rtol=1e-5, atol=1e-6)  # (2y)^2
+    # the same exchange with the overlap switched off (SEG3D_DDP_OVERLAP=0): one exchange after the pass, same numbers
+    sp.zero_grad(set_to_none=True)
+    sp._overlap = False
+    sp(xs[rank])["a"].square().mean().backward()
+    assert sp.exchanges == 4
+    for p, ref_g in zip(net.body.parameters(), want):
+        assert torch.allclose(p.grad, ref_g, rtol=1e-5, atol=1e-7)
+    sp._overlap = True
+
+    class Blind(torch.nn.Module):  # a training forward whose result carries no differentiable tensor: refuse, do not diverge
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+
+        def forward(self, x):
+            return {"n": 3, "t": (x * self.w).detach()}
+
+    blind = D.SceneParallel(Blind())
+    try:
+        blind(torch.ones(3))
+        raise AssertionError("expected a RuntimeError")
+    except RuntimeError as e:
+        assert "no differentiable tensor" in str(e)
+    blind.close()
+    # deferral is scoped to the wrapper's own parameters: a parameter of another module is not exempt
+    assert net.body[0].weight in ops_mod.DEFER_OWNED and blind.module.w not in ops_mod.DEFER_OWNED
     sp.eval()
     with torch.no_grad():
         assert sp(xs[rank])["a"].shape == (xs[rank].shape[0], 4)

@@ -530,13 +530,18 @@ def test_plain_ddp_wrapper_gets_finished_gradients():
 
 
 def test_scene_parallel_wrapper_exchanges_after_the_pass():
-    """dist.wrap_data_parallel's default wrapper (dist.SceneParallel): nothing hangs on the AccumulateGrad nodes, the
-    backward pass keeps its deferred weight-gradient join, and ONE exchange out of a flat arena follows the pass.  Two gloo
-    ranks share the card: both end with the mean of the two single-rank gradients, with deferral ON in their processes."""
-    env = {"SEG3D_DDP_WRAPPER": "native"}
+    """dist.wrap_data_parallel's default wrapper (dist.SceneParallel): only arrival counters hang on the AccumulateGrad
+    nodes, the backward pass keeps its deferred weight-gradient join, and the exchange runs out of a flat arena -- after the
+    first pass, slice by slice during the second.  Two gloo ranks share the card: both end with the mean of the two
+    single-rank gradients, with deferral ON in their processes."""
+    env = {"SEG3D_DDP_WRAPPER": "native", "SEG3D_DDP_PASSES": "2", "SEG3D_DDP_BUCKET_MB": "8"}
     both = _ddp_ranks(2, "gloo", env)
     singles = [_ddp_ranks(1, "gloo", {"SEG3D_DDP_ONLY_SCENE": str(r), "SEG3D_BENCH_DIST": "1"})[0] for r in range(2)]
     _check_ddp_mean(both, singles, deferred=True)
+    # round 5: the second pass exchanged most slices from the weight-gradient stream while the pass was still running
+    # (flushed sums + one multi-tensor copy + all-reduce per slice, ordered behind the gradient kernels on that stream)
+    for r in both:
+        assert r["slices"] >= 8 and r["early_slices"] >= r["slices"] // 2, r
 
 
 def test_two_gpus_rccl_all_reduce():
