@@ -42,7 +42,7 @@ ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
 WORKLOADS = {
     "one_sweep": "waymo_one_sweep (BASELINE configs[1])",
     "cylinder": "waymo_one_sweep_cylinder (BASELINE configs[2] geometry)",
-    "multi_sweeps": "waymo_multi_sweeps + image features (BASELINE configs[3], 3 sweeps)",
+    "multi_sweeps": "waymo_multi_sweeps + image features (BASELINE configs[3])",
     "dense2m": "synthetic dense scene, 2 M points @0.02 m voxels in a 28.8 m x 28.8 m x 1.28 m block "
                "(BASELINE configs[4] / SURVEY 8d Config 5)",
 }
@@ -81,6 +81,9 @@ def parse():
                          "feature maps of the INFERENCE forward are stored in bf16 (fp32 accumulate; which tensors may be rounded "
                          "was decided per op family, tools/bf16_storage_probe.py); `fwd_only` is then that forward and the line "
                          "carries its agreement with the fp32-storage forward of the same weights.  The training step is unchanged.")
+    ap.add_argument("--sweeps", type=int, default=0,
+                    help="multi_sweeps only: DATASET.NUM_SWEEPS (0 = 3, what configs/waymo_multi_sweeps.yaml:2-4 sets; 5 = "
+                         "DATASET.MAX_NUM_SWEEPS and BASELINE configs[3]'s wording, ~800 k rows per scene)")
     ap.add_argument("--sync-bn", action="store_true", help="tools/train.py --sync_bn: SyncBatchNorm over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true",
@@ -321,6 +324,10 @@ def main():
     elif args.workload == "multi_sweeps":  # configs/waymo_multi_sweeps.yaml:1-4 + USE_IMAGE_FEATURE
         cfg.DATASET.USE_MULTI_SWEEPS = True
         cfg.DATASET.USE_IMAGE_FEATURE = True
+        if args.sweeps:
+            if not 1 <= args.sweeps <= cfg.DATASET.MAX_NUM_SWEEPS:
+                raise SystemExit(f"--sweeps {args.sweeps}: 1 .. DATASET.MAX_NUM_SWEEPS = {cfg.DATASET.MAX_NUM_SWEEPS}")
+            cfg.DATASET.NUM_SWEEPS = args.sweeps
     elif args.workload == "dense2m":  # BASELINE configs[4]: same 1440 x 1440 x 64 grid at 0.02 m
         cfg.DATASET.POINT_CLOUD_RANGE = list(scene.DENSE_RANGE)
         cfg.DATASET.VOXEL_SIZE = list(scene.DENSE_VOXEL)
@@ -360,7 +367,11 @@ def main():
         sample, s_cur, s_img = scenes_np[0], n_cur[0], None
         if args.workload == "multi_sweeps":
             k = min(n_cpu, n_cur[0]) if n_cpu else n_cur[0]
-            sample = np.concatenate([sample[:k], sample[n_cur[0]: n_cur[0] + 2 * k]], axis=0)
+            # history rows: the same number from EVERY history sweep (2k in all), so that a 5-sweep sample sees all five lags
+            n_hist = max(cfg.DATASET.NUM_SWEEPS - 1, 1)
+            per = (sample.shape[0] - n_cur[0]) // n_hist
+            take = min(2 * k // n_hist, per)
+            sample = np.concatenate([sample[:k]] + [sample[n_cur[0] + h * per: n_cur[0] + h * per + take] for h in range(n_hist)], axis=0)
             s_cur, s_img = k, images[0][:k]
         elif n_cpu:
             sample = sample[:n_cpu]
@@ -525,8 +536,75 @@ def main():
         pts = sum(pts_per_step[(args.warmup + i) % len(resident)] for i in range(args.steps))
         return D.aggregate_throughput(sec, pts, dev)
 
+    def idle_probe(first, k):
+        """Is the GPU ever waiting for the host inside a step?  (the profiled timeline shows 4 ms of gaps per
+        step behind three copies -- before the fused SGD and before two elementwise kernels -- but a profiled host is a slow
+        host.)  Un-profiled, with HIP events on the main stream:
+          steady  -- k more steps as in the timed loop; events at the start of a step, behind backward() and behind
+                     opt.step(); host clocks at the same points;
+          fed     -- k steps each enqueued behind a 50 ms device-side sleep, so the whole step is in the queue before its first
+                     kernel may start: the step's GPU time with the host out of the picture.
+        gpu_idle_ms = steady main-stream time per step (start of a step to the start of the next) minus the fed step's --
+        what the host, the launch path or the pipeline hand-over add to a step.  Runs after the timed region."""
+        if dev.type != "cuda" or not hasattr(torch.cuda, "_sleep"):
+            return None
+        main = torch.cuda.current_stream(dev)
+
+        def ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(main)
+            return e
+
+        def one(i, rec):
+            j = i % len(resident)
+            h0 = time.perf_counter()
+            b = next_batch(i)
+            e0 = ev()
+            opt.zero_grad(set_to_none=True)
+            res = net(b)
+            data = {"point_labels": labels[j], "voxel_labels": voxel_labels[j], "batch_size": b["batch_size"]}
+            loss = _losses.compute_loss(res, data, criterion, cfg)
+            loss.backward()
+            h1 = time.perf_counter()
+            e1 = ev()
+            opt.step()
+            h2 = time.perf_counter()
+            e2 = ev()
+            prefetch(i)
+            h3 = time.perf_counter()
+            rec.append((e0, e1, e2, h0, h1, h2, h3))
+
+        steady, fed = [], []
+        for i in range(k + 1):
+            one(first + i, steady)
+        torch.cuda.synchronize(dev)
+        for i in range(k):
+            torch.cuda._sleep(5_000_000)  # s_memtime ticks at 100 MHz on gfx950: 50 ms, twice the host's enqueue time of a step
+            one(first + k + 1 + i, fed)
+            torch.cuda.synchronize(dev)
+        ms = lambda a, b: a.elapsed_time(b)  # noqa: E731
+        mean = lambda v: float(np.mean(v)) if len(v) else 0.0  # noqa: E731
+        steady_step = mean([ms(steady[i][0], steady[i + 1][0]) for i in range(k)])
+        fed_step = mean([ms(r[0], r[2]) for r in fed])
+        return {"steps": k,
+                "host_enqueue_ms": round(mean([(r[5] - r[3]) * 1e3 for r in steady[:k]]), 3),
+                "host_enqueue_opt_step_ms": round(mean([(r[5] - r[4]) * 1e3 for r in steady[:k]]), 3),
+                "host_in_prefetch_ms": round(mean([(r[6] - r[5]) * 1e3 for r in steady[:k]]), 3),
+                "gpu_step_ms_steady": round(steady_step, 3),
+                "gpu_step_ms_fed": round(fed_step, 3),
+                "gpu_opt_step_ms_steady": round(mean([ms(r[1], r[2]) for r in steady[:k]]), 3),
+                "gpu_opt_step_ms_fed": round(mean([ms(r[1], r[2]) for r in fed]), 3),
+                "gpu_between_steps_ms": round(mean([ms(steady[i][2], steady[i + 1][0]) for i in range(k)]), 3),
+                "gpu_idle_ms": round(max(steady_step - fed_step, 0.0), 3),
+                "note": "HIP events on the main stream, no profiler: steady = consecutive steps as timed; fed = each step enqueued "
+                        "whole behind a 50 ms device-side sleep (the host cannot be late); gpu_idle_ms = steady - fed per step; "
+                        "gpu_opt_step_ms = backward's last kernel to the fused SGD's last (the profiled timeline shows a 2.1 ms "
+                        "gap there); gpu_between_steps_ms = SGD's end to the next step's first kernel (pipeline hand-over)"}
+
     weights_l1 = None
     nosync_ms = None
+    idle_report = None
+    extra_steps = 0
     if train:
         net.train()
         dt, n_pts = timed(train_step, "train")
@@ -535,6 +613,10 @@ def main():
         # digit (SEG3D_WGRAD_STREAM=0 / --no-pipeline give the single-stream reference); under DDP every rank must hold
         # the same value
         weights_l1 = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+        if world == 1 and os.environ.get("SEG3D_BENCH_IDLE_PROBE", "1") != "0":
+            k_idle = min(max(args.steps, 1), 6)
+            idle_report = idle_probe(args.warmup + args.steps, k_idle)
+            extra_steps = 2 * k_idle + 1 if idle_report is not None else 0
         if distributed and world > 1:
             # what the gradient exchange costs on the critical path: the same steps with DDP's all-reduce switched off
             # (no_sync), after the fingerprint -- the ranks' weights diverge from here on, only eval timing follows
@@ -600,7 +682,8 @@ def main():
                                                                      if args.storage == "bf16" else ""))
             if _ops.CONV_PRECISION == "bf16x3" else "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload] + ": synthetic scene, "
+            "config": {"workload": WORKLOADS[args.workload] + (f", {cfg.DATASET.NUM_SWEEPS} sweeps = {int(resident[0].shape[0])} rows/step"
+                                                               if args.workload == "multi_sweeps" else "") + ": synthetic scene, "
                                    f"{pts_per_step[0]} pts/step/GPU, voxel {ds.voxel_size}, grid {ds.grid_size.tolist()}, {step_desc}",
                        "mode": args.mode, "segmentor": args.segmentor, "scenes_per_step_per_gpu": args.batch,
                        "voxels": int(b0["voxel_coords"].shape[0]), "parallelism": f"dp{world}",
@@ -616,6 +699,8 @@ def main():
             "conv_layers": [{k: l[k] for k in ("rows", "cin", "cout", "us", "bound", "frac")} for l in per_layer],
             "attention_roofline": ATTENTION_REPORT if args.segmentor == "segformer" else None,
         }
+        if idle_report is not None:
+            out["idle"] = idle_report
         if storage_report is not None:
             storage_report["fwd_speedup"] = round(storage_report["fwd_ms_per_step_fp32_storage"] / (dt_f / args.steps * 1e3), 3)
             out["storage"] = storage_report
@@ -675,7 +760,7 @@ def main():
                 _, o_res, o_coords, o_ids = cpu_baseline(*parity_sample, cfg, ds, model)
                 after = parity_report(*parity_sample, ds, model, dev, o_res, o_coords, o_ids)
                 out["parity"]["after_training"] = {k: after[k] for k in after if k.startswith("max_") or k.endswith("bit_exact")}
-                out["parity"]["after_training"]["steps"] = args.steps + args.warmup
+                out["parity"]["after_training"]["steps"] = args.steps + args.warmup + extra_steps
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_layers.json"), "w") as f:
             json.dump(per_layer, f, indent=1)

@@ -185,14 +185,18 @@ def test_direct_tiles_are_bit_identical_too(dev, cin, cout):
             assert torch.equal(old, new), float((old - new).abs().max())
 
 
-def test_tiled_conv_matches_the_fp64_oracle(dev):
+@pytest.mark.parametrize("cin,cout", [(96, 192), (64, 48), (48, 48), (48, 32), (96, 48), (192, 128), (384, 96)])
+def test_tiled_conv_matches_the_fp64_oracle(dev, cin, cout):
+    """The tile kernel against the fp64 oracle DIRECTLY (not against the per-pair kernel it replaces), forward and input
+    gradient, one case per wave layout: 192-column (96 -> 192), the offset-split layouts of the narrow layers -- cout 48 / 32
+    forward and, through the transposed pack, cin 48 / 32 in the input gradient: the layouts whose summation order is their
+    own --, 128-column and 96-column workgroups."""
     from oracle import sparse_conv as sc
     from openseg3d_amd import ops, spconv
     assert ops.CONV_TILED
     coords, shape, bs = _random_sites(5000, [10, 36, 36], 2, 5)
     ref = sc.Sites(coords, shape)
-    cin, cout = 96, 192
-    torch.manual_seed(0)
+    torch.manual_seed(cin * 1000 + cout)
     x = torch.randn(coords.shape[0], cin, dtype=torch.float64, requires_grad=True)
     w = (torch.randn(cout, 3, 3, 3, cin, dtype=torch.float64) / (27 * cin) ** 0.5).requires_grad_()
     y_ref = sc.subm_conv(x, ref, w)
@@ -204,9 +208,13 @@ def test_tiled_conv_matches_the_fp64_oracle(dev):
     xin = x.detach().float().to(dev).requires_grad_()
     out = conv(spconv.SparseConvTensor(xin, torch.from_numpy(coords).to(dev), shape, bs))
     assert out.level.subm_plan() is not None
+    from openseg3d_amd import _lib
+    assert _lib.load().seg3d_spconv_tiled_supported(cin, cout)  # the forward takes the tile schedule (the input gradient too
+    # wherever its own cout = cin is a supported width: 48, 96, 192, 384 here; 64 falls to the per-pair kernel)
     assert float((out.features.detach().cpu().double() - y_ref.detach()).abs().max()) < 1e-4
     out.features.backward(g.float().to(dev))
     assert float((xin.grad.cpu().double() - x.grad).abs().max()) < 1e-4
+    assert float((conv.weight.grad.cpu().double() - w.grad).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
 
 
 @pytest.mark.parametrize("cin,cout", [(96, 192), (192, 96), (64, 48), (96, 32), (384, 384)])

@@ -116,6 +116,13 @@ def test_bench_prints_one_contract_line():
     assert f["fwd_only_ms_per_step"] > 20.0  # exact-fp32 products run at 1/16 of the bf16 MFMA rate (default path: ~13 ms)
     assert len(d["conv_layers"]) == 20 and {l["bound"] for l in d["conv_layers"]} == {"hbm", "mfma_bf16x3"}
     assert d["fwd_only"]["value"] > d["value"]
+    # round 5: the un-profiled answer to "does the GPU wait for the host inside a step" (HIP events on the main stream;
+    # steady consecutive steps against steps enqueued whole behind a device-side sleep)
+    idle = d["idle"]
+    for key in ("host_enqueue_ms", "gpu_idle_ms", "gpu_step_ms_steady", "gpu_step_ms_fed", "gpu_opt_step_ms_steady",
+                "gpu_opt_step_ms_fed", "gpu_between_steps_ms", "host_in_prefetch_ms"):
+        assert key in idle and idle[key] >= 0.0, key
+    assert idle["gpu_step_ms_fed"] > 10.0 and idle["host_enqueue_ms"] > 1.0
 
 
 def test_bench_distributed_path_single_rank_rehearsal():
@@ -188,15 +195,16 @@ def test_headline_scene_logits_match_oracle():
 
 @pytest.mark.parametrize("workload,extra,n_expect", [
     ("cylinder", ["--batch", "4", "--scenes", "1"], 174633),        # configs/waymo_one_sweep_cylinder.yaml:2-4, BASELINE configs[2]
-    ("multi_sweeps", ["--batch", "2", "--scenes", "1"], 30000),      # configs/waymo_multi_sweeps.yaml:1-4 + image, configs[3]
+    ("multi_sweeps", ["--batch", "2", "--scenes", "1", "--sweeps", "5"], 30000),  # configs/waymo_multi_sweeps.yaml:1-4 + image at
+    # DATASET.MAX_NUM_SWEEPS = 5 (~800 k rows per scene: BASELINE configs[3] as worded; the YAML's own NUM_SWEEPS is 3)
     ("dense2m", ["--scenes", "1"], 150000),                           # BASELINE configs[4]: 2 M points @0.02 m, 150 k-point crop
 ])
 def test_full_size_configs_logits_match_oracle(workload, extra, n_expect):
     """BASELINE configs[2] and configs[3] at their bench sizes, driver-visible: `bench.py --workload ...` builds the
     batch (4 cylinder scenes with the device cart2polar / 2 scenes of 3 sweeps with image features and the DeepFusion
     kNN), and its `parity` object compares scene 0 with the CPU oracle on the same weights: voxel ids and every rulebook
-    bit-exact, per-point logits within 1e-3 (the multi-sweep sample is the first 30 000 current-sweep rows + 60 000
-    history rows: the oracle's brute-force kNN sets that limit, bench.py:311-322)."""
+    bit-exact, per-point logits within 1e-3 (the multi-sweep sample is the first 30 000 current-sweep rows + 15 000 rows of
+    each of the four history sweeps: the oracle's brute-force kNN sets that limit, bench.py `n_cpu`)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--mode", "fwd", "--steps", "1",
                           "--warmup", "1"] + extra, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -208,6 +216,8 @@ def test_full_size_configs_logits_match_oracle(workload, extra, n_expect):
         # is up to 4 ulp off: the points that fall into ANOTHER voxel because of it are counted, and they are few
         moved = par["cylinder_phi"]
         assert moved["n_points"] == n_expect and moved["frac"] <= 1e-4, moved
+    if workload == "multi_sweeps":
+        assert "5 sweeps" in line["config"]["workload"], line["config"]["workload"]
     assert par["n_points"] == n_expect, par
     assert par["voxel_ids_bit_exact"] is True and par["rulebook_bit_exact"] is True, par
     assert par["max_abs_logit_diff"] < 1e-3 and par["max_abs_voxel_logit_diff"] < 1e-3 and par["max_abs_aux_logit_diff"] < 1e-3, par
@@ -709,3 +719,49 @@ def test_parameter_gradients_match_oracle_when_the_switches_are_linear(monkeypat
     assert len(worst) > 300  # (the rest: parameters whose gradient is identically zero in this graph)
     for rel, k in worst:
         assert rel <= (2e-2 if k.endswith(".tau") else 1e-3), worst[:8]
+
+
+def test_spnet_error_after_training_is_conditioning_not_the_split_products():
+    """Round 4's open parity question (row f3): after 13 bench steps on random labels SPNet's logits stand 1.3 apart from
+    the oracle's (rel 2e-3) where they stood 2.7e-4 (rel 2.6e-6) at the starting weights.  tools/spnet_parity_probe.py
+    localises it (profiles/r05_spnet_parity_probe_*.txt): the bench's SGD drives the stride-8 features to |7.6e5| and the
+    auxiliary logits to |2.4e6|, and OCR's SpatialGatherModule takes a softmax over the voxels of THOSE logits (ocr.py:22-31)
+    -- one fp32 ulp there is 0.25, i.e. a factor e^0.25 on a softmax weight.  The oracle's own fp32 forward is 1e-2 (relative)
+    away from its fp64 forward at that stage; the GPU in exact-fp32 products 2.5e-3; the split products 4.5e-2.  Up to that
+    softmax every stage stays within 4e-6 of fp64 on the trained weights in BOTH arithmetics.  Asserted here, against the
+    fp64 oracle: the well-conditioned stages at 2e-5, the OCR stage within 30x of the fp32 oracle's own error, the point
+    logits at rel 5e-3 (VERDICT r4 item 1's bar)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import spnet_parity_probe as P
+    from openseg3d_amd import batch as B, losses, ops, scene, segformer
+    dev = torch.device("cuda:0")
+    cfg, ds = P.setup()
+    torch.manual_seed(0)
+    model = segformer.build_segmentor(cfg, ds).to(dev)
+    crit = losses.build_criterion(cfg, ds)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4, fused=True)  # bench.py's setting
+    scenes = [scene.make_scene(s) for s in range(4)]
+    res_dev = [B.collate_points([s], dev) for s in scenes]
+    labels = [torch.randint(0, 22, (s.shape[0],), device=dev) for s in scenes]
+    model.train()
+    for i in range(13):
+        j = i % 4
+        b = B.batch_from_resident(res_dev[j], [scenes[j].shape[0]], ds.voxel_size, ds.point_cloud_range)
+        vl = ops.prepare_voxel_labels(b["point_voxel_ids"], labels[j], b["voxel_coords"].shape[0], ignore_index=ds.ignore_index).long()
+        opt.zero_grad(set_to_none=True)
+        loss = losses.compute_loss(model(b), {"point_labels": labels[j], "voxel_labels": vl, "batch_size": 1}, crit, cfg)
+        loss.backward()
+        opt.step()
+    model.eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    f64 = P.oracle_forward(scenes[0], cfg, ds, sd, torch.float64)
+    f32 = P.oracle_forward(scenes[0], cfg, ds, sd, torch.float32)
+    rows = P.table(f64, {"oracle_f32": f32, "gpu": P.gpu_forward(model, scenes[0], ds, dev)})
+    assert rows["aux_voxel_out"]["max_abs"] > 1e4, rows["aux_voxel_out"]  # the regime the record was taken in
+    for name in ("conv1", "conv2", "conv3", "conv4", "aux_voxel_out"):  # in front of the ill-conditioned softmax
+        assert rows[name]["gpu"]["rel"] <= 2e-5, (name, rows[name])
+    assert rows["ocr"]["oracle_f32"]["rel"] >= 50 * rows["conv2"]["oracle_f32"]["rel"], rows["ocr"]  # fp32 itself loses it there
+    assert rows["ocr"]["gpu"]["rel"] <= 30 * rows["ocr"]["oracle_f32"]["rel"], rows["ocr"]
+    for name in ("voxel_out", "point_out"):
+        assert rows[name]["gpu"]["rel"] <= 5e-3, (name, rows[name])
