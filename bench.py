@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true",
                     help="skip the child run that times the same step with exact-fp32 products (SEG3D_CONV_PRECISION=fp32)")
+    ap.add_argument("--no-fp64-oracle", action="store_true",
+                    help="skip the second, float64 evaluation of the CPU oracle on the parity sample (`parity.vs_fp64_oracle`; "
+                         "run by default for the headline workload only: it doubles the oracle's time)")
     ap.add_argument("--no-pipeline", action="store_true", help="build each step's batch and index plan at the start of the step "
                     "instead of on the pipeline stream during the previous step")
     ap.add_argument("--cpu-points", type=int, default=-1,
@@ -230,9 +233,12 @@ def conv_roofline(model, batch, dev):
             "launches": n_layers, "bytes_per_launch": int(tot_bytes / n), "us_per_launch": round(tot_ms * 1e3 / n, 2)}, per_layer
 
 
-def cpu_baseline(pts, n_cur, image, cfg, ds, model):
+def cpu_baseline(pts, n_cur, image, cfg, ds, model, dtype=torch.float32):
     """The oracle (CPU restatement of the reference algorithm) on the host cores: the sample's points, same weights,
     eval forward.  pts: rows of one scene (all sweeps), n_cur: its current-sweep rows, image: [n_cur, 28] or None.
+    dtype float64: the same forward evaluated in double precision (weights and inputs widened exactly; the position
+    embedding keeps its float32 values, the reference computes it in float32) -- the reference's FUNCTION without its
+    float32 round-off, against which both the float32 oracle and the GPU path can be placed.
     Returns (report, oracle result dict, oracle voxel coords, oracle point->voxel ids)."""
     from oracle import index_ops, model as omodel
     # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe a larger affinity mask
@@ -241,29 +247,31 @@ def cpu_baseline(pts, n_cur, image, cfg, ds, model):
     print(f"[bench] cpu_baseline: oracle forward of {pts.shape[0]} points on {cores} host threads ...", file=sys.stderr, flush=True)
     t0 = time.time()
     coords, ids = index_ops.voxelize(pts, ds.voxel_size, ds.point_cloud_range)
-    batch = {"points": torch.from_numpy(np.pad(pts, ((0, 0), (1, 0)))).float(),
+    batch = {"points": torch.from_numpy(np.pad(pts, ((0, 0), (1, 0)))).to(dtype),
              "voxel_coords": torch.from_numpy(np.pad(coords, ((0, 0), (1, 0)))).float(),
              "point_voxel_ids": torch.from_numpy(ids).long(), "batch_size": 1,
              "point_id_offset": torch.tensor([float(n_cur)])}
     if image is not None:
-        batch["point_image_features"] = image.detach().cpu()
+        batch["point_image_features"] = image.detach().cpu().to(dtype)
     ocfg = {"grid_size": index_ops.grid_size_of(ds.voxel_size, ds.point_cloud_range),
             "batching_info": [{int(k): v for k, v in lvl.items()} for lvl in cfg.MODEL.BATCHING_INFO],
             "window_shape": cfg.MODEL.WINDOW_SHAPE, "depths": cfg.MODEL.DEPTHS,
             "use_multi_sweeps": bool(ds.use_multi_sweeps), "use_image_feature": bool(ds.use_image_feature)}
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sd = {k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
     with torch.no_grad():
         res = (omodel.spnet_forward if cfg.MODEL.SEGMENTOR == "spnet" else omodel.segformer_forward)(batch, sd, ocfg)
     dt = time.time() - t0
-    report = {"value": round(n_cur / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
+    report = {"value": round(n_cur / dt, 1), "unit": "points/s", "cores": cores, "kind": "port", "dtype": str(dtype).split(".")[-1],
               "sample": f"1 forward (voxelize + {cfg.MODEL.SEGMENTOR} eval) of {n_cur} points ({pts.shape[0]} rows with history "
                         f"sweeps) of scene seed 0, {coords.shape[0]} voxels, {dt:.1f} s, torch.set_num_threads({cores})"}
     return report, res, coords, ids
 
 
-def parity_report(pts, n_cur, image, ds, model, dev, oracle_res, oracle_coords, oracle_ids):
+def parity_report(pts, n_cur, image, ds, model, dev, oracle_res, oracle_coords, oracle_ids, oracle_f64=None):
     """GPU path vs the oracle on the same sample and the same weights (the `logit parity` half of the metric):
-    per-point logits within 1e-3, voxel ids and rulebooks bit-exact (BASELINE.json north_star)."""
+    per-point logits within 1e-3, voxel ids and rulebooks bit-exact (BASELINE.json north_star).  oracle_f64: the result
+    of the same oracle evaluated in float64 -- then `vs_fp64_oracle` places BOTH float32 computations (the CPU oracle's and
+    the GPU's) against it: at |logit| ~ 200 the float32 oracle's own round-off is a large part of `max_abs_logit_diff`."""
     from openseg3d_amd import batch as B
     b = B.batch_from_resident(B.collate_points([pts], dev), [n_cur], ds.voxel_size, ds.point_cloud_range, image)
     gpu_coords = b["voxel_coords"].int().cpu().numpy()
@@ -291,6 +299,14 @@ def parity_report(pts, n_cur, image, ds, model, dev, oracle_res, oracle_coords, 
     if ids_ok:
         out["max_abs_logit"] = float(oracle_res["point_out"].abs().max())
         out["max_rel_logit_diff"] = out["max_abs_logit_diff"] / max(out["max_abs_logit"], 1e-30)
+    if ids_ok and oracle_f64 is not None:
+        v64 = {}
+        for key, name in (("point_out", "logit"), ("voxel_out", "voxel_logit"), ("aux_voxel_out", "aux_logit")):
+            v64[f"gpu_max_abs_{name}_diff"] = float((res[key].double().cpu() - oracle_f64[key]).abs().max())
+            v64[f"oracle_fp32_max_abs_{name}_diff"] = float((oracle_res[key].double() - oracle_f64[key]).abs().max())
+        v64["note"] = ("the same oracle evaluated in float64 as the reference point: how far the float32 CPU oracle and the GPU "
+                       "path each are from the reference's function without float32 round-off")
+        out["vs_fp64_oracle"] = v64
     # what the checker itself is pinned by
     out["pinned_by"] = ("oracle/ = CPU restatement checked against outputs of the reference's own Python (tests/golden/*.npz, "
                         "regenerable with tests/golden/make_golden.py) for voxelizer, window partition, attention, "
@@ -381,7 +397,11 @@ def main():
             sample = _ops.cart2polar(torch.from_numpy(sample).to(dev)).cpu().numpy()
         model.eval()
         report, o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
-        baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids))
+        o64 = None
+        if args.workload == "one_sweep" and not args.no_fp64_oracle:
+            o64 = cpu_baseline(sample, s_cur, s_img, cfg, ds, model, dtype=torch.float64)[1]
+        baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids, o64))
+        del o64
         parity_sample = (sample, s_cur, s_img)
         if cyl:
             # how many points land in ANOTHER voxel when phi comes from numpy's float32 arctan2 (what the reference's loader
