@@ -80,7 +80,9 @@ def parse():
                     help="bf16 = BASELINE configs[4]'s reduced-precision mode as this build defines it (SURVEY D7): the sparse-conv "
                          "feature maps of the INFERENCE forward are stored in bf16 (fp32 accumulate; which tensors may be rounded "
                          "was decided per op family, tools/bf16_storage_probe.py); `fwd_only` is then that forward and the line "
-                         "carries its agreement with the fp32-storage forward of the same weights.  The training step is unchanged.")
+                         "carries its agreement with the fp32-storage forward of the same weights.  The TRAINING step saves bf16 "
+                         "copies of the rows its weight gradients multiply with (graph tensors and gradients stay fp32; "
+                         "SEG3D_TRAIN_STORAGE=bf16) and is timed after the same steps with fp32 copies (`train_storage`).")
     ap.add_argument("--sweeps", type=int, default=0,
                     help="multi_sweeps only: DATASET.NUM_SWEEPS (0 = 3, what configs/waymo_multi_sweeps.yaml:2-4 sets; 5 = "
                          "DATASET.MAX_NUM_SWEEPS and BASELINE configs[3]'s wording, ~800 k rows per scene)")
@@ -625,9 +627,31 @@ def main():
     nosync_ms = None
     idle_report = None
     extra_steps = 0
+    train_storage = None
+    peak_bytes = None
     if train:
         net.train()
+        if args.storage == "bf16" and dev.type == "cuda":
+            # the same steps with the fp32 copies first (same process, same box), then with the opt-in bf16 copies: the
+            # headline `value` of a --storage bf16 line is the second
+            torch.cuda.reset_peak_memory_stats(dev)
+            dt32, n32 = timed(train_step, "train_fp32_copies")
+            train_storage = {"ms_per_step_fp32_copies": round(dt32 / args.steps * 1e3, 3),
+                             "peak_memory_gb_fp32_copies": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 3)}
+            _ops.TRAIN_STORAGE = "bf16"
+        if dev.type == "cuda":
+            torch.cuda.reset_peak_memory_stats(dev)
         dt, n_pts = timed(train_step, "train")
+        if dev.type == "cuda":
+            peak_bytes = torch.cuda.max_memory_allocated(dev)
+        if train_storage is not None:
+            train_storage.update({"ms_per_step": round(dt / args.steps * 1e3, 3), "peak_memory_gb": round(peak_bytes / 2 ** 30, 3),
+                                  "mode": "bf16 COPIES of the rows each sparse-conv / Linear weight gradient multiplies with are "
+                                          "what the forward saves for the backward (graph tensors and all gradients stay fp32; "
+                                          "weight-gradient products: 2 MFMAs, 8-byte gathers, no split of x)",
+                                  "stated_tolerance": "loss and all input-path gradients identical; conv / Linear weight gradients "
+                                                      "within 1e-2 of their largest entry (tests/test_gpu_training.py::"
+                                                      "test_bf16_training_copies_stay_within_their_stated_tolerance)"})
         # fingerprint of the weights after the timed steps (fp64 sum of |w| over every parameter): the kernels are
         # deterministic, so the streams, the deferred joins and the input pipeline must leave it unchanged to the last
         # digit (SEG3D_WGRAD_STREAM=0 / --no-pipeline give the single-stream reference); under DDP every rank must hold
@@ -698,7 +722,8 @@ def main():
             "value": round(n_pts / dt, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 storage/accumulate, bf16x3 products" + ("; fwd_only: bf16 storage of the sparse-conv feature maps"
+            "dtype": ("f32 storage/accumulate, bf16x3 products" + ("; training: bf16 copies of the weight-gradient operands saved for "
+                                                                     "backward; fwd_only: bf16 storage of the sparse-conv feature maps"
                                                                      if args.storage == "bf16" else ""))
             if _ops.CONV_PRECISION == "bf16x3" else "f32",
             "data": "synthetic",
@@ -721,6 +746,10 @@ def main():
         }
         if idle_report is not None:
             out["idle"] = idle_report
+        if peak_bytes is not None:
+            out["peak_memory_gb"] = round(peak_bytes / 2 ** 30, 3)
+        if train_storage is not None:
+            out["train_storage"] = train_storage
         if storage_report is not None:
             storage_report["fwd_speedup"] = round(storage_report["fwd_ms_per_step_fp32_storage"] / (dt_f / args.steps * 1e3), 3)
             out["storage"] = storage_report

@@ -257,6 +257,14 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
 int seg3d_spconv_wgrad_partials(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int64_t m_in,
                                 int32_t cin, int32_t cout, void* workspace, size_t workspace_bytes, int32_t* chunks,
                                 void* stream);
+/* The same with the layer's input rows stored as bf16 [m_in, cin] -- BASELINE configs[4] names bf16, the reference has no
+ * reduced-precision mode, so the mode is build-defined and OPT-IN (SEG3D_TRAIN_STORAGE=bf16): the sparse-conv /
+ * Linear autograd functions (call sites spconv_utils.py:13-32, point_transformer_layer.py:260-298) keep a bf16 COPY of their
+ * input for the backward pass instead of the fp32 tensor; every tensor of the graph, and therefore every gradient, stays
+ * fp32.  A bf16 row is its own high half: 8-byte gathers, no split of x, two MFMAs per product; dy stays fp32 / split. */
+int seg3d_spconv_wgrad_partials_xbf16(const uint16_t* x_bf16, const float* dy, const int32_t* nbr, int64_t m_out,
+                                      int64_t m_in, int32_t cin, int32_t cout, void* workspace, size_t workspace_bytes,
+                                      int32_t* chunks, void* stream);
 
 /* a6, a22  weight gradient of the dense per-point / per-voxel Linear layers (segformer.py:21-32,58-76,
  * point_transformer_layer.py:260-276, cosine_msa.py:58-63,403):  dw[cout][cin] = dy^T . x  over m rows.
@@ -277,6 +285,10 @@ int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, int32_t cin, 
  * layer's own GEMM / reduction kernels (point_transformer_layer.py:260-298). */
 int seg3d_linear_wgrad_partials(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout, int32_t with_bias,
                                 void* workspace, size_t workspace_bytes, int32_t* chunks, void* stream);
+/* ... with x stored as bf16 [m, cin] (the opt-in training copies, see seg3d_spconv_wgrad_partials_xbf16) */
+int seg3d_linear_wgrad_partials_xbf16(const uint16_t* x_bf16, const float* dy, int64_t m, int32_t cin, int32_t cout,
+                                      int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks,
+                                      void* stream);
 int seg3d_reduce_partials(const float* part, int32_t chunks, int64_t n, int64_t nw, float* dw, float* db, void* stream);
 int seg3d_reduce_partials_batched(const void* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
 /* a6  exact-fp32 variant for the per-point MLPs (segformer.py:21-32,58-76), whose split-bf16 forward error would land

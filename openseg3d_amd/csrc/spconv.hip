@@ -22,8 +22,8 @@ int spconv_split_fwd_io(const void* x, const int32_t* nbr, int64_t m_out, const 
 int spconv_split_fwd(const float* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                      const float* addend, const int32_t* row_order, int cin, int cout, float* y, int relu, hipStream_t st);
 size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout);  // wgrad_split.hip
-int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
-                       void* workspace, size_t workspace_bytes, hipStream_t st, int32_t* chunks_out);
+int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
+                       void* workspace, size_t workspace_bytes, hipStream_t st, int32_t* chunks_out, bool x_bf16);
 
 namespace {
 
@@ -388,7 +388,7 @@ int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int6
     hipStream_t st = as_stream(stream);
     if (m_out > 0 && (!x || !dy || !nbr)) return SEG3D_EINVAL;
     // split-bf16: partial blocks per row chunk in the workspace, summed in a fixed order (writes all of dw)
-    if (m_out > 0 && (flags & 4)) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, workspace, workspace_bytes, st, nullptr);
+    if (m_out > 0 && (flags & 4)) return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, dw, workspace, workspace_bytes, st, nullptr, false);
     SEG3D_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)27 * cin * cout * sizeof(float), st));
     if (m_out == 0) return SEG3D_OK;
     const int ja = pick_j(cin), jb = pick_j(cout);
@@ -410,7 +410,19 @@ int seg3d_spconv_wgrad_partials(const float* x, const float* dy, const int32_t* 
     *chunks = 0;
     if (m_out == 0) return SEG3D_OK;
     if (!x || !dy || !nbr) return SEG3D_EINVAL;
-    return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, nullptr, workspace, workspace_bytes, as_stream(stream), chunks);
+    return wgrad_split_sparse(x, dy, nbr, m_out, cin, cout, nullptr, workspace, workspace_bytes, as_stream(stream), chunks, false);
+}
+
+/* seg3d_spconv_wgrad_partials with the x rows stored as bf16 [m_in, cin] (the opt-in copies a training forward saves for its
+ * backward, SEG3D_TRAIN_STORAGE=bf16): a bf16 row is its own high half -- 8-byte gathers, no split of x, two MFMAs per product. */
+int seg3d_spconv_wgrad_partials_xbf16(const uint16_t* x_bf16, const float* dy, const int32_t* nbr, int64_t m_out, int64_t m_in,
+                                      int32_t cin, int32_t cout, void* workspace, size_t workspace_bytes, int32_t* chunks,
+                                      void* stream) {
+    if (m_out < 0 || m_in < 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || !chunks) return SEG3D_EINVAL;
+    *chunks = 0;
+    if (m_out == 0) return SEG3D_OK;
+    if (!x_bf16 || !dy || !nbr) return SEG3D_EINVAL;
+    return wgrad_split_sparse(x_bf16, dy, nbr, m_out, cin, cout, nullptr, workspace, workspace_bytes, as_stream(stream), chunks, true);
 }
 
 }  // extern "C"

@@ -55,10 +55,32 @@ Plan plan(int64_t m, int cin, int cout) {
     return p;
 }
 
-__global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// bf16 fragment of channel `comp` (0..3) of a lane's quad from 8 rows of 4 bf16 each (q[i] = row i: {ch0 | ch1 << 16, ch2 | ch3 << 16})
+__device__ __forceinline__ bf16x8 frag_from_bf16_rows(const uint2* q, int comp) {
+    u32x4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t a = (comp & 2) ? q[2 * j].y : q[2 * j].x, b = (comp & 2) ? q[2 * j + 1].y : q[2 * j + 1].x;
+        h[j] = (comp & 1) ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16));
+    }
+    return __builtin_bit_cast(bf16x8, h);
+}
+
+// acc += a . b for a split-bf16 `a` and a `b` that IS bf16 (a bf16 row is its own high half: no a_hi * b_lo term)
+__device__ __forceinline__ f32x4 mfma2(const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
+    return acc;
+}
+
+// XB: the x rows are stored as bf16 (the opt-in bf16 copies a training forward saves for its backward, SEG3D_TRAIN_STORAGE=bf16):
+// 8-byte loads, no split of x, two MFMAs per product.  dy is always fp32.
+template <bool XB>
+__global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                int64_t m_rows, int cin, int cout, int rows_per_chunk,
                                                                int nbi, int tiles, float* __restrict__ part,
                                                                int want_bias) {
+    const float* x = static_cast<const float*>(x_v);
     __shared__ __attribute__((aligned(16))) float red[64 * 64];  // block sum [co_local][ci_local]
     __shared__ float red_b[kWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,7 +96,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
     // stored, so no masking is needed.  Lane offsets are 32-bit and added to a wave-uniform row pointer.
     const bool a_ok = co0 + 4 * cq < cout, b_ok = ci0 + 4 * cq < cin;
     const uint32_t yoff = (uint32_t)((8 * rg * cout + (a_ok ? co0 + 4 * cq : 0)) * 4);
-    const uint32_t xoff = (uint32_t)((8 * rg * cin + (b_ok ? ci0 + 4 * cq : 0)) * 4);
+    const uint32_t xoff = (uint32_t)((8 * rg * cin + (b_ok ? ci0 + 4 * cq : 0)) * (XB ? 2 : 4));
     const bool want_db = want_bias && bi == 0;
 
     f32x4 acc[4][4];
@@ -84,20 +106,36 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 db_acc = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xr[8], yr[8];
-    bf16x8 b_hi[4], b_lo[4];
+    f32x4 xr[XB ? 1 : 8], yr[8];
+    uint2 xq[XB ? 8 : 1];
+    bf16x8 b_hi[4], b_lo[XB ? 1 : 4];
     auto load_rows = [&](const float* src, int ld, uint32_t off, int step, f32x4(&dst)[8]) {
         const char* base = reinterpret_cast<const char*>(src + (r_begin + 32 * (int64_t)step) * ld);  // wave-uniform
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)i * ld * 4 + off);
     };
+    auto load_x = [&](int step) {
+        if constexpr (XB) {
+            const char* base = static_cast<const char*>(x_v) + (r_begin + 32 * (int64_t)step) * cin * 2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xq[i] = *reinterpret_cast<const uint2*>(base + (size_t)i * cin * 2 + xoff);
+        } else {
+            const char* base = reinterpret_cast<const char*>(x + (r_begin + 32 * (int64_t)step) * cin);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const f32x4*>(base + (size_t)i * cin * 4 + xoff);
+        }
+    };
     auto make_b = [&]() {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            float v[8];
+            if constexpr (XB) {
+                b_hi[b] = frag_from_bf16_rows(xq, b);
+            } else {
+                float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = xr[i][b];
-            split_frag(v, &b_hi[b], &b_lo[b]);
+                for (int i = 0; i < 8; ++i) v[i] = xr[i][b];
+                split_frag(v, &b_hi[b], &b_lo[b]);
+            }
         }
     };
     auto multiply = [&]() {
@@ -113,7 +151,10 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
             bf16x8 a_hi, a_lo;
             split_frag(v, &a_hi, &a_lo);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+            for (int b = 0; b < 4; ++b) {
+                if constexpr (XB) acc[a][b] = mfma2(a_hi, a_lo, b_hi[b], acc[a][b]);
+                else acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+            }
         }
     };
     // full 32-row steps: the x rows of the wave's next step are requested as soon as this step's are converted,
@@ -121,13 +162,13 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
     const int n_full = (int)((r_end - r_begin) / 32);
     int s = wave;
     if (s < n_full) {
-        load_rows(x, cin, xoff, s, xr);
+        load_x(s);
         load_rows(dy, cout, yoff, s, yr);
     }
     for (; s < n_full; s += kWaves) {
         const bool more = s + kWaves < n_full;
         make_b();
-        if (more) load_rows(x, cin, xoff, s + kWaves, xr);
+        if (more) load_x(s + kWaves);
         multiply();
         if (more) load_rows(dy, cout, yoff, s + kWaves, yr);
     }
@@ -139,9 +180,14 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const float* _
         for (int i = 0; i < 8; ++i) {
             const bool ok = r0 + i < r_end;
             const int64_t r = ok ? r0 + i : r_end - 1;
-            const f32x4 vx = *reinterpret_cast<const f32x4*>(x + r * cin + (b_ok ? ci0 + 4 * cq : 0));
             const f32x4 vy = *reinterpret_cast<const f32x4*>(dy + r * cout + (a_ok ? co0 + 4 * cq : 0));
-            xr[i] = ok ? vx : z;
+            if constexpr (XB) {
+                const uint2 vx = *reinterpret_cast<const uint2*>(static_cast<const char*>(x_v) + (r * cin + (b_ok ? ci0 + 4 * cq : 0)) * 2);
+                xq[i] = ok ? vx : make_uint2(0u, 0u);
+            } else {
+                const f32x4 vx = *reinterpret_cast<const f32x4*>(x + r * cin + (b_ok ? ci0 + 4 * cq : 0));
+                xr[i] = ok ? vx : z;
+            }
             yr[i] = ok ? vy : z;
         }
         make_b();
@@ -279,9 +325,8 @@ extern "C" size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int
 
 // The two halves of seg3d_linear_wgrad apart: partial blocks now, their fixed-order sum later (alone, or batched with the
 // other pending sums of a backward pass).  *chunks receives the number of partial blocks written (0 when m == 0).
-extern "C" int seg3d_linear_wgrad_partials(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout,
-                                           int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks,
-                                           void* stream) {
+static int linear_wgrad_partials(const void* x, bool x_bf16, const float* dy, int64_t m, int32_t cin, int32_t cout,
+                                 int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks, void* stream) {
     if (m < 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || !chunks) return SEG3D_EINVAL;
     if (m > 0 && (!x || !dy)) return SEG3D_EINVAL;
     if (workspace_bytes < seg3d_linear_wgrad_workspace_bytes(m, cin, cout) || (m > 0 && !workspace)) return SEG3D_EINVAL;
@@ -290,11 +335,27 @@ extern "C" int seg3d_linear_wgrad_partials(const float* x, const float* dy, int6
     const Plan p = plan(m, cin, cout);
     const int tiles = p.nbo * p.nbi;
     const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
-    hipLaunchKernelGGL(wgrad_dense_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), x, dy, m, cin, cout,
-                       (int)p.rows, p.nbi, tiles, static_cast<float*>(workspace), with_bias ? 1 : 0);
+    if (x_bf16)
+        hipLaunchKernelGGL(wgrad_dense_kernel<true>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), x, dy, m, cin, cout,
+                           (int)p.rows, p.nbi, tiles, static_cast<float*>(workspace), with_bias ? 1 : 0);
+    else
+        hipLaunchKernelGGL(wgrad_dense_kernel<false>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), x, dy, m, cin, cout,
+                           (int)p.rows, p.nbi, tiles, static_cast<float*>(workspace), with_bias ? 1 : 0);
     SEG3D_CHECK_LAUNCH();
     *chunks = p.chunks;
     return SEG3D_OK;
+}
+
+extern "C" int seg3d_linear_wgrad_partials(const float* x, const float* dy, int64_t m, int32_t cin, int32_t cout,
+                                           int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks,
+                                           void* stream) {
+    return linear_wgrad_partials(x, false, dy, m, cin, cout, with_bias, workspace, workspace_bytes, chunks, stream);
+}
+
+extern "C" int seg3d_linear_wgrad_partials_xbf16(const uint16_t* x_bf16, const float* dy, int64_t m, int32_t cin, int32_t cout,
+                                                 int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks,
+                                                 void* stream) {
+    return linear_wgrad_partials(x_bf16, true, dy, m, cin, cout, with_bias, workspace, workspace_bytes, chunks, stream);
 }
 
 extern "C" int seg3d_reduce_partials(const float* part, int32_t chunks, int64_t n, int64_t nw, float* dw, float* db,
@@ -323,7 +384,7 @@ extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, in
     if (m > 0) {
         const int tiles = p.nbo * p.nbi;
         const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
-        hipLaunchKernelGGL(wgrad_dense_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows, p.nbi,
+        hipLaunchKernelGGL(wgrad_dense_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows, p.nbi,
                            tiles, part, db ? 1 : 0);
         SEG3D_CHECK_LAUNCH();
     }

@@ -32,6 +32,25 @@ constexpr int kWaves = 4;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kRing = 128;  // pairs per wave ring: at most 31 left over + 64 new
 
+// XB variants (x rows stored as bf16: the opt-in copies a training forward saves for its backward, SEG3D_TRAIN_STORAGE=bf16):
+// a bf16 row is its own high half -- 8-byte gathers, no split of x, two MFMAs per product.  dy is always fp32.
+// bf16 fragment of channel `comp` (0..3) of a lane's quad from 8 rows of 4 bf16 each (q[i] = {ch0 | ch1 << 16, ch2 | ch3 << 16})
+__device__ __forceinline__ bf16x8 frag_from_bf16_rows(const uint2* q, int comp) {
+    u32x4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t a = (comp & 2) ? q[2 * j].y : q[2 * j].x, b = (comp & 2) ? q[2 * j + 1].y : q[2 * j + 1].x;
+        h[j] = (comp & 1) ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16));
+    }
+    return __builtin_bit_cast(bf16x8, h);
+}
+
+__device__ __forceinline__ f32x4 mfma2(const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b, acc, 0, 0, 0);
+    return acc;
+}
+
 struct Plan {
     int nbo, nbi;
     int chunks;
@@ -60,10 +79,12 @@ Plan plan(int64_t m, int cin, int cout) {
     return p;
 }
 
-__global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <bool XB>
+__global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                     const int32_t* __restrict__ nbr, int64_t m_rows,
                                                                     int cin, int cout, int rows_per_chunk, int nbi,
                                                                     int tiles, int units, float* __restrict__ part) {
+    const float* x = static_cast<const float*>(x_v);
     __shared__ __attribute__((aligned(16))) float red[64 * 64];  // block sum [co_local][ci_local]
     __shared__ int2 ring[kWaves][kRing];                         // (input row, output row) pairs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,6 +99,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
     const int64_t r_end = r_begin + rows_per_chunk < m_rows ? r_begin + rows_per_chunk : m_rows;
     const int32_t* nk = nbr + (int64_t)k * m_rows;
     const float* px = x + (ci0 + 4 * cq < cin ? ci0 + 4 * cq : 0);
+    const uint16_t* pxb = static_cast<const uint16_t*>(x_v) + (ci0 + 4 * cq < cin ? ci0 + 4 * cq : 0);
     const float* py = dy + (co0 + 4 * cq < cout ? co0 + 4 * cq : 0);
     int2* my = ring[wave];
 
@@ -119,20 +141,25 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
         __builtin_amdgcn_wave_barrier();
     };
 
-    f32x4 xr[8], yr[8];
-    bf16x8 b_hi[4], b_lo[4];
+    f32x4 xr[XB ? 1 : 8], yr[8];
+    uint2 xq[XB ? 8 : 1];
+    bf16x8 b_hi[4], b_lo[XB ? 1 : 4];
     // rows of the step that starts at ring position h0; slots >= valid are zero
     auto load_x = [&](int h0, int valid) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = 8 * rg + i;
             const int2 p = my[(h0 + (e < valid ? e : 0)) & (kRing - 1)];
-            xr[i] = *reinterpret_cast<const f32x4*>(px + (int64_t)p.x * cin);
+            if constexpr (XB) xq[i] = *reinterpret_cast<const uint2*>(pxb + (int64_t)p.x * cin);
+            else xr[i] = *reinterpret_cast<const f32x4*>(px + (int64_t)p.x * cin);
         }
         if (valid < 32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (8 * rg + i >= valid) xr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (8 * rg + i >= valid) {
+                    if constexpr (XB) xq[i] = make_uint2(0u, 0u);
+                    else xr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
         }
     };
     auto load_y = [&](int h0, int valid) {
@@ -151,10 +178,14 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
     auto make_b = [&]() {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            float v[8];
+            if constexpr (XB) {
+                b_hi[b] = frag_from_bf16_rows(xq, b);
+            } else {
+                float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = xr[i][b];
-            split_frag(v, &b_hi[b], &b_lo[b]);
+                for (int i = 0; i < 8; ++i) v[i] = xr[i][b];
+                split_frag(v, &b_hi[b], &b_lo[b]);
+            }
         }
     };
     auto multiply = [&]() {
@@ -166,7 +197,10 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
             bf16x8 a_hi, a_lo;
             split_frag(v, &a_hi, &a_lo);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+            for (int b = 0; b < 4; ++b) {
+                if constexpr (XB) acc[a][b] = mfma2(a_hi, a_lo, b_hi[b], acc[a][b]);
+                else acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+            }
         }
     };
 
@@ -224,10 +258,12 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const float* 
 // s+1 are issued before the MFMAs of step s.
 constexpr int kRing2 = 512;  // pairs: at most 31 left over + 256 new
 
-__global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <bool XB, int DEPTH>
+__global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                          const int32_t* __restrict__ nbr, int64_t m_rows,
                                                                          int cin, int cout, int rows_per_chunk, int nbi,
                                                                          int tiles, int units, float* __restrict__ part) {
+    const float* x = static_cast<const float*>(x_v);
     __shared__ __attribute__((aligned(16))) uint4 img[2][4][2][4][64];  // [buffer][slab][hi|lo][row group][record] 64 KiB
     __shared__ int2 ring[kRing2];
     __shared__ int wave_cnt[2][kWaves];
@@ -248,6 +284,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const fl
     const int ld = stage_dy ? cout : cin;
     const int ch = (stage_dy ? co0 : ci0) + 64 * (wave & 1) + 4 * cq;
     const float* src = (stage_dy ? dy : x) + (ch < ld ? ch : 0);
+    const uint16_t* srcb = static_cast<const uint16_t*>(x_v) + (ch < ld ? ch : 0);  // (XB: the x slabs of waves 2, 3)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -294,64 +331,110 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const fl
         __syncthreads();  // ring writes visible
     };
 
-    f32x4 raw[8];
-    auto load_slab = [&](int h0, int valid) {
+    f32x4 raw[8], raw2[DEPTH == 2 ? 8 : 1];
+    uint2 rawb[XB ? 8 : 1], rawb2[(XB && DEPTH == 2) ? 8 : 1];
+    auto load_into = [&](f32x4* r, uint2* rb, int h0, int valid) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = 8 * rg + i;
             const int2 p = ring[(h0 + (e < valid ? e : 0)) & (kRing2 - 1)];
-            raw[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)(stage_dy ? p.y : p.x) * ld);
+            if (XB && !stage_dy) {  // wave-uniform
+                if constexpr (XB) rb[i] = *reinterpret_cast<const uint2*>(srcb + (int64_t)p.x * ld);
+            } else {
+                r[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)(stage_dy ? p.y : p.x) * ld);
+            }
         }
         if (valid < 32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (8 * rg + i >= valid) raw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (8 * rg + i >= valid) {
+                    r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (XB) rb[i] = make_uint2(0u, 0u);
+                }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash_from = [&](const f32x4* r, const uint2* rb, int buf) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
+            if (XB && !stage_dy) {  // bf16 rows: the record is the row's own bits, there is no low plane
+                if constexpr (XB) img[buf][wave][0][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, frag_from_bf16_rows(rb, jj));
+                continue;
+            }
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = raw[i][jj];
+            for (int i = 0; i < 8; ++i) v[i] = r[i][jj];
             bf16x8 hi, lo;
             split_frag(v, &hi, &lo);
             img[buf][wave][0][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, hi);
             img[buf][wave][1][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, lo);
         }
     };
+    auto load_slab = [&](int h0, int valid) { load_into(raw, rawb, h0, valid); };
+    auto stash = [&](int buf) { stash_from(raw, rawb, buf); };
     auto multiply = [&](int buf) {
-        bf16x8 b_hi[4], b_lo[4];
+        bf16x8 b_hi[4], b_lo[XB ? 1 : 4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             b_hi[b] = __builtin_bit_cast(bf16x8, img[buf][2 + wb][0][rg][b * 16 + cq]);
-            b_lo[b] = __builtin_bit_cast(bf16x8, img[buf][2 + wb][1][rg][b * 16 + cq]);
+            if constexpr (!XB) b_lo[b] = __builtin_bit_cast(bf16x8, img[buf][2 + wb][1][rg][b * 16 + cq]);
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const bf16x8 a_hi = __builtin_bit_cast(bf16x8, img[buf][wa][0][rg][a * 16 + cq]);
             const bf16x8 a_lo = __builtin_bit_cast(bf16x8, img[buf][wa][1][rg][a * 16 + cq]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+            for (int b = 0; b < 4; ++b) {
+                if constexpr (XB) acc[a][b] = mfma2(a_hi, a_lo, b_hi[b], acc[a][b]);
+                else acc[a][b] = mfma3(a_hi, a_lo, b_hi[b], b_lo[b], acc[a][b]);
+            }
         }
     };
 
-    refill();
-    int valid = tail - head < 32 ? tail - head : 32;
     int buf = 0;
-    if (valid > 0) {
-        load_slab(head, valid);
-        stash(0);
-    }
-    while (valid > 0) {
-        head += valid;
-        refill();  // also the barrier that publishes image `buf`
-        const int next = tail - head < 32 ? tail - head : 32;
-        if (next > 0) load_slab(head, next);
-        multiply(buf);
-        if (next > 0) stash(buf ^ 1);
-        buf ^= 1;
-        valid = next;
+    if constexpr (DEPTH == 1) {
+        refill();
+        int valid = tail - head < 32 ? tail - head : 32;
+        if (valid > 0) {
+            load_slab(head, valid);
+            stash(0);
+        }
+        while (valid > 0) {
+            head += valid;
+            refill();  // also the barrier that publishes image `buf`
+            const int next = tail - head < 32 ? tail - head : 32;
+            if (next > 0) load_slab(head, next);
+            multiply(buf);
+            if (next > 0) stash(buf ^ 1);
+            buf ^= 1;
+            valid = next;
+        }
+    } else {
+        // Two steps of gathers in flight: the rows of step s+2 are requested before the MFMAs of step s and converted after
+        // the MFMAs of step s+1 (two register sets, roles alternate), so a gather has two multiplies to arrive instead of one.
+        // head = ring position of the next step to be requested; fetch() is executed by every wave alike (barriers inside).
+        auto fetch = [&](f32x4* r, uint2* rb) {
+            refill();  // (>= 32 pairs ahead or the table exhausted) + the barrier that publishes the image stashed last
+            const int v = tail - head < 32 ? tail - head : 32;
+            if (v > 0) load_into(r, rb, head, v);
+            head += v;
+            return v;
+        };
+        int va = fetch(raw, rawb);                      // step 0
+        int vb = va > 0 ? fetch(raw2, rawb2) : 0;       // step 1
+        if (va > 0) stash_from(raw, rawb, 0);
+        while (va > 0) {
+            // image `buf` = step s (from set A), set B holds the rows of step s+1
+            va = vb > 0 ? fetch(raw, rawb) : (refill(), 0);    // step s+2 into set A; its barrier publishes image `buf`
+            multiply(buf);
+            if (vb > 0) stash_from(raw2, rawb2, buf ^ 1);
+            buf ^= 1;
+            if (vb == 0) break;
+            // image `buf` = step s+1 (from set B), set A holds the rows of step s+2
+            vb = va > 0 ? fetch(raw2, rawb2) : (refill(), 0);  // step s+3 into set B
+            multiply(buf);
+            if (va > 0) stash_from(raw, rawb, buf ^ 1);
+            buf ^= 1;
+        }
     }
     __syncthreads();  // all reads of the images done: reuse them as the store staging area
 
@@ -383,8 +466,8 @@ size_t wgrad_split_sparse_workspace_bytes(int64_t m_out, int cin, int cout) {
 }
 
 // dw == nullptr: the partial blocks only (their fixed-order sum is queued by the caller); *chunks_out = their count
-int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
-                       void* workspace, size_t workspace_bytes, hipStream_t st, int32_t* chunks_out) {
+int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64_t m_out, int cin, int cout, float* dw,
+                       void* workspace, size_t workspace_bytes, hipStream_t st, int32_t* chunks_out, bool x_bf16) {
     if (workspace_bytes < wgrad_split_sparse_workspace_bytes(m_out, cin, cout) || !workspace) return SEG3D_EINVAL;
     const Plan p = plan(m_out, cin, cout);
     float* part = static_cast<float*>(workspace);
@@ -406,13 +489,31 @@ int wgrad_split_sparse(const float* x, const float* dy, const int32_t* nbr, int6
     if ((fits128 || wide_padded) && !narrow_only) {
         const int nbo = (cout + 127) / 128, nbi = (cin + 127) / 128, tiles = nbo * nbi;
         const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
-        hipLaunchKernelGGL(wgrad_sparse_wide_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
-                           (int)p.rows, nbi, tiles, units, part);
+        // SEG3D_WGRAD_DEPTH (A/B): gather steps in flight per wave (1 or 2)
+        static const int depth = [] {
+            const char* e = getenv("SEG3D_WGRAD_DEPTH");
+            const int v = e ? atoi(e) : 1;
+            return v == 2 ? 2 : 1;
+        }();
+#define SEG3D_LAUNCH_WIDE(XB_, D_)                                                                                             \
+    hipLaunchKernelGGL((wgrad_sparse_wide_kernel<XB_, D_>), dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout, \
+                       (int)p.rows, nbi, tiles, units, part)
+        if (x_bf16) {  // (two register sets of both row formats do not fit: 464 bytes of scratch at depth 2)
+            SEG3D_LAUNCH_WIDE(true, 1);
+        } else {
+            if (depth == 2) SEG3D_LAUNCH_WIDE(false, 2);
+            else SEG3D_LAUNCH_WIDE(false, 1);
+        }
+#undef SEG3D_LAUNCH_WIDE
     } else {
         const int tiles = p.nbo * p.nbi;
         const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
-        hipLaunchKernelGGL(wgrad_sparse_kernel, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
-                           (int)p.rows, p.nbi, tiles, units, part);
+        if (x_bf16)
+            hipLaunchKernelGGL(wgrad_sparse_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
+                               (int)p.rows, p.nbi, tiles, units, part);
+        else
+            hipLaunchKernelGGL(wgrad_sparse_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
+                               (int)p.rows, p.nbi, tiles, units, part);
     }
     SEG3D_CHECK_LAUNCH();
     if (chunks_out) *chunks_out = p.chunks;

@@ -79,6 +79,10 @@ class _WgradFork:
     def fork(self, *keep_alive):
         """Stream handle for a weight-gradient launch whose operands are already enqueued on the current stream."""
         if not self.on:
+            # (bf16 training copies are written on the side stream, _saved_rows: a launch that stays on the current stream
+            # -- the stream was switched off between forward and backward -- must wait for them)
+            if self.device.type == "cuda" and any(torch.is_tensor(t) and t.dtype == torch.bfloat16 for t in keep_alive):
+                torch.cuda.current_stream(self.device).wait_stream(side_stream(self.device))
             return _stream()
         ev = torch.cuda.Event()
         ev.record(self.main)
@@ -847,6 +851,38 @@ STORAGE = os.environ.get("SEG3D_STORAGE", "fp32")
 STORAGE_ROUND_INPUTS = os.environ.get("SEG3D_STORAGE_ROUND_INPUTS", "1") != "0"
 
 
+# Opt-in bf16 COPIES for the backward pass (BASELINE configs[4] names bf16; SURVEY D7: build-defined).  With
+# SEG3D_TRAIN_STORAGE=bf16 the sparse-conv / Linear / encoder-layer functions save a bf16 copy of the rows their WEIGHT
+# gradient will multiply with instead of the fp32 tensor (which is then free to be released as soon as the forward has moved
+# on): every tensor of the autograd graph stays fp32, so every gradient stays fp32 -- what changes is the precision of one
+# operand of the weight-gradient products (8 significant bits instead of 16) and their cost (a bf16 row is its own high
+# half: 8-byte gathers, no split, two MFMAs per product).  Tolerance stated against this repo's own fp32-copy path in
+# tests/test_gpu_training.py::test_bf16_training_copies_stay_within_their_stated_tolerance.
+TRAIN_STORAGE = os.environ.get("SEG3D_TRAIN_STORAGE", "fp32")
+
+
+def _saved_rows(x):
+    """What a training forward keeps of the rows `x` for its weight gradient: x itself, or its bf16 copy (opt-in).  The
+    copy is made on the WEIGHT-GRADIENT stream: that stream idles during the forward pass and is the only reader of the copy
+    (the weight-gradient kernels of the backward pass are launched there, in order behind it), so the conversion leaves the
+    forward's main chain and needs no join (on the main chain the ~150 conversion passes of a dense 2 M-point scene cost
+    19 ms per step: 288 -> 307 ms)."""
+    if TRAIN_STORAGE not in ("fp32", "bf16"):
+        raise _lib.Seg3dError(f"SEG3D_TRAIN_STORAGE must be 'fp32' or 'bf16', got {TRAIN_STORAGE!r}")
+    if not (TRAIN_STORAGE == "bf16" and CONV_PRECISION == "bf16x3" and x.dtype == torch.float32 and x.is_cuda):
+        return x
+    if not WGRAD_STREAM:
+        return x.to(torch.bfloat16)
+    main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        y = x.to(torch.bfloat16)  # (allocated from the side stream's pool: the backward's readers run on that stream)
+    x.record_stream(side)  # x's block must not be handed to a later main-stream tensor before the conversion has run
+    return y
+
+
 def conv_storage_bf16():
     if STORAGE not in ("fp32", "bf16"):
         raise _lib.Seg3dError(f"SEG3D_STORAGE must be 'fp32' or 'bf16', got {STORAGE!r}")
@@ -899,7 +935,7 @@ class _SparseConvFn(torch.autograd.Function):
         if packed is None:
             packed = pack_weight(weight, PACK_FWD)
         y = _conv_apply(x, nbr, packed, None if bias is None else _f32c(bias), cin, cout, order, plan)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(_saved_rows(x) if (ctx.needs_input_grad[1] and cin % 16 == 0 and cout % 16 == 0) else x, weight)
         ctx.nbr, ctx.nbr_t, ctx.t_flags, ctx.has_bias, ctx.order_t = nbr, nbr_t, t_flags, bias is not None, order_t
         ctx.plan_t = plan_t
         ctx.bias_param = bias
@@ -919,11 +955,13 @@ class _SparseConvFn(torch.autograd.Function):
             if _precision_flag() & PACK_SPLIT_BF16:
                 # partial blocks now; their fixed-order sum joins the pass's other parameter-gradient sums (one launch)
                 chunks = ctypes.c_int32(0)
-                _lib.call("seg3d_spconv_wgrad_partials", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
+                _lib.call("seg3d_spconv_wgrad_partials_xbf16" if x.dtype == torch.bfloat16 else "seg3d_spconv_wgrad_partials",
+                          _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
                           _ptr(ws), ws_bytes, ctypes.byref(chunks), fk.fork(ws, dy, x, ctx.nbr))
                 n = 27 * cin * cout
                 fk.add_reduce(ws, chunks.value, n, n, dw.data_ptr(), 0, ws)
             else:
+                x = _f32c(x)
                 _lib.call("seg3d_spconv_wgrad", _ptr(x), _ptr(dy), _ptr(ctx.nbr), dy.shape[0], x.shape[0], cin, cout,
                           _precision_flag(), _ptr(dw), _ptr(ws), ws_bytes, fk.fork(ws, dy, x, ctx.nbr))
         if ctx.needs_input_grad[0]:
@@ -1010,7 +1048,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, exact):
         x = _f32c(x)
         cout, cin = weight.shape
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(_saved_rows(x) if ctx.needs_input_grad[1] else x, weight)
         ctx.has_bias, ctx.exact = bias is not None, exact
         ctx.bias_param = bias  # (a reference for the deferred-join bookkeeping of the weight-gradient stream)
         if exact:  # exact-fp32 MFMA kernel (rocBLAS for odd shapes); only the weight gradient uses the split kernel
@@ -1629,7 +1667,8 @@ class _AttnInProjFn(torch.autograd.Function):
         xp = x + pos
         qk = _linear_apply(xp, _linear_pack(w_in[: 2 * c], 0), b_in[: 2 * c], c, 2 * c)
         v = _linear_apply(x, _linear_pack(w_in[2 * c:], 0), b_in[2 * c:], c, c)
-        ctx.save_for_backward(x, xp, w_in)
+        keep = ctx.needs_input_grad[2]
+        ctx.save_for_backward(_saved_rows(x) if keep else x, _saved_rows(xp) if keep else xp, w_in)
         ctx.b_in = b_in
         return qk, v
 
@@ -1703,7 +1742,8 @@ def _linear_wgrad_into(fk, x, dy, cin, cout, dw_ptr, db_ptr, *keep):
     ws_bytes = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, cin, cout)
     ws = _workspace(ws_bytes, dy.device)
     chunks = ctypes.c_int32(0)
-    _lib.call("seg3d_linear_wgrad_partials", _ptr(x), _ptr(dy), m, cin, cout, 1 if db_ptr else 0, _ptr(ws), ws_bytes,
+    _lib.call("seg3d_linear_wgrad_partials_xbf16" if x.dtype == torch.bfloat16 else "seg3d_linear_wgrad_partials",
+              _ptr(x), _ptr(dy), m, cin, cout, 1 if db_ptr else 0, _ptr(ws), ws_bytes,
               ctypes.byref(chunks), fk.fork(ws, x, dy, *keep))
     fk.add_reduce(ws, chunks.value, cin * cout + cout, cin * cout, dw_ptr, db_ptr, *keep)
 
@@ -1769,7 +1809,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             m = _linear_apply(g, _linear_pack(w2, 0), b2, hid, c)
             x2 = _LayerNormResidualFn.forward(c_n2, m, x1, g2, be2, eps2, s2)
         ctx.parts = (c_in, c_at, c_n1, c_n2)
-        ctx.save_for_backward(o, x1, h, g, w_out, w1, w2)
+        ctx.save_for_backward(_saved_rows(o), _saved_rows(x1), h, _saved_rows(g), w_out, w1, w2)
         ctx.bias_params = (b_out, b1, b2)
         ctx.norm_params = (g1, be1, g2, be2)
         return x2
