@@ -245,6 +245,10 @@ int seg3d_spconv_fwd_tiled_bf16(const void* x, int32_t x_bf16, const int32_t* nb
  * Same effect as the SEG3D_CONV_NBT environment variable, which is read once when the library loads.
  * The reference has no counterpart (spconv chooses its own tiles). */
 int seg3d_debug_set_conv_nbt(int32_t nbt);
+/* Test aid for the opt-in row-streaming schedule of the dense Linear layers with cin <= 192 (csrc/linear_stream.hip, the
+ * nn.Linear calls of point_transformer_layer.py:260-298 / cosine_msa.py:58-63,403; bit-identical to the default schedule,
+ * measured slower, SEG3D_LINEAR_STREAM=1): 1 = on, 0 = off, -1 = the environment's choice. */
+int seg3d_debug_set_linear_stream(int32_t on);
 size_t seg3d_spconv_wgrad_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout);
 int seg3d_spconv_wgrad(const float* x, const float* dy, const int32_t* nbr, int64_t m_out,
                        int64_t m_in, int32_t cin, int32_t cout, int32_t flags /* bit2: split-bf16 */,

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
@@ -54,6 +54,7 @@ SIGNATURES = {
     "seg3d_spconv_fwd_tiled": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p]),
     "seg3d_spconv_fwd_tiled_bf16": (ctypes.c_int, [_p, _i32, _p, _p, _i64, _i64, _p, _i32, _p, _p, _i32, _i32, _i32, _p, _p]),
     "seg3d_debug_set_conv_nbt": (ctypes.c_int, [_i32]),
+    "seg3d_debug_set_linear_stream": (ctypes.c_int, [_i32]),
     "seg3d_spconv_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "seg3d_spconv_wgrad": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "seg3d_spconv_wgrad_partials": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _sz, _p, _p]),

@@ -595,11 +595,21 @@ extern "C" int seg3d_debug_set_conv_nbt(int32_t nbt) {
     return SEG3D_OK;
 }
 
+// linear_stream.hip: the row-streaming schedule of the dense Linear layers with cin <= 192 (1 = not its shape)
+int linear_stream_fwd(const float* x, int64_t m, const void* wp, const float* bias, const float* addend, int cin, int cout,
+                      float* y, int io, hipStream_t st);
+
 static int split_fwd_impl(const void* x, const int32_t* nbr, int64_t m_out, const void* wp, const float* bias,
                           const void* addend, const int32_t* row_order, int cin, int cout, void* y, int relu, int io,
                           hipStream_t st, const float* x_add, LnEpilogue ln) {
     if (x_add && (nbr || io != 0)) return SEG3D_EINVAL;  // the second summand exists for Linear layers only
     if (io == 4 && (nbr || !addend)) return SEG3D_EINVAL;  // ... and so does the elementwise factor
+    if (!nbr && !row_order && !relu && !x_add && (io == 0 || io == 4) && g_forced_nbt.load(std::memory_order_relaxed) == 0) {
+        // dense rows, W slice in registers, rows streamed (bit-identical results; SEG3D_LINEAR_STREAM=0 switches it off)
+        const int rc = linear_stream_fwd(static_cast<const float*>(x), m_out, wp, bias, static_cast<const float*>(addend), cin,
+                                         cout, static_cast<float*>(y), io, st);
+        if (rc != 1) return rc;
+    }
     // Column blocks per workgroup: 192 columns while the launch has >= 400 row tiles; the deepest level has few rows
     // (19k) and 384+ columns: 128-column workgroups put it on the chip in ONE resident round (153 row tiles x 3 = 459 of
     // 512 slots; 96 columns = 612 = a second, mostly empty round) and gather each row 3 times instead of 4

@@ -57,6 +57,23 @@ struct Plan {
     int64_t rows;  // output rows per chunk (multiple of 64)
 };
 
+// Longest units first.  In a submanifold table the centre offset (k = 13) pairs EVERY row with itself while the other 26
+// offsets hold a quarter of the rows or fewer: a centre unit is a workgroup four times as long as the rest, and in (chunk, k)
+// order the last chunk's centre unit is dispatched in the launch's last round and ends long after everything else (level 4:
+// 54 workgroups of ~100 steps among 1 404 of ~25 on 512 slots).  Units 0 .. chunks - 1 are therefore the centre units of all
+// chunks, the other offsets follow chunk by chunk.  (Strided / inverse tables have no dominant offset: the order is harmless.)
+__device__ __forceinline__ void unit_to_chunk_offset(int unit, int n_chunks, int* chunk, int* k) {
+    if (unit < n_chunks) {
+        *chunk = unit;
+        *k = 13;
+    } else {
+        const int u = unit - n_chunks;
+        const int kk = u % 26;
+        *chunk = u / 26;
+        *k = kk + (kk >= 13 ? 1 : 0);
+    }
+}
+
 Plan plan(int64_t m, int cin, int cout) {
     Plan p{(cout + 63) / 64, (cin + 63) / 64, 0, 64};
     if (m <= 0) return p;
@@ -83,7 +100,8 @@ template <bool XB>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                     const int32_t* __restrict__ nbr, int64_t m_rows,
                                                                     int cin, int cout, int rows_per_chunk, int nbi,
-                                                                    int tiles, int units, float* __restrict__ part) {
+                                                                    int tiles, int units, float* __restrict__ part,
+                                                                    int center_first) {
     const float* x = static_cast<const float*>(x_v);
     __shared__ __attribute__((aligned(16))) float red[64 * 64];  // block sum [co_local][ci_local]
     __shared__ int2 ring[kWaves][kRing];                         // (input row, output row) pairs
@@ -92,7 +110,8 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const void* _
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int unit = (j / tiles) * 8 + xcd, tile = j % tiles;
     if (unit >= units) return;  // padding of the XCD-aligned grid (whole workgroup)
-    const int chunk = unit / 27, k = unit % 27;
+    int chunk = unit / 27, k = unit % 27;
+    if (center_first) unit_to_chunk_offset(unit, units / 27, &chunk, &k);
     const int bi = tile % nbi, bo = tile / nbi;
     const int ci0 = bi * 64, co0 = bo * 64;
     const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
@@ -262,7 +281,8 @@ template <bool XB, int DEPTH>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                          const int32_t* __restrict__ nbr, int64_t m_rows,
                                                                          int cin, int cout, int rows_per_chunk, int nbi,
-                                                                         int tiles, int units, float* __restrict__ part) {
+                                                                         int tiles, int units, float* __restrict__ part,
+                                                                         int center_first) {
     const float* x = static_cast<const float*>(x_v);
     __shared__ __attribute__((aligned(16))) uint4 img[2][4][2][4][64];  // [buffer][slab][hi|lo][row group][record] 64 KiB
     __shared__ int2 ring[kRing2];
@@ -273,7 +293,8 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int unit = (j / tiles) * 8 + xcd, tile = j % tiles;
     if (unit >= units) return;  // padding of the XCD-aligned grid (whole workgroup)
-    const int chunk = unit / 27, k = unit % 27;
+    int chunk = unit / 27, k = unit % 27;
+    if (center_first) unit_to_chunk_offset(unit, units / 27, &chunk, &k);
     const int bi = tile % nbi, bo = tile / nbi;
     const int ci0 = bi * 128, co0 = bo * 128;
     const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
@@ -473,6 +494,11 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
     float* part = static_cast<float*>(workspace);
     const int units = p.chunks * 27;
     static const bool narrow_only = getenv("SEG3D_WGRAD_NARROW") != nullptr;  // A/B switch for profiling
+    // SEG3D_WGRAD_CENTER_FIRST (A/B): 0 = units in (chunk, offset) order (round 4)
+    static const int center_first = [] {
+        const char* e = getenv("SEG3D_WGRAD_CENTER_FIRST");
+        return (e && atoi(e) == 0) ? 0 : 1;
+    }();
     // 128-wide blocks only where they add no padding (C = 256, 384, 768; not 192 = 1.5 blocks)
     const bool fits128 = ((cin + 127) / 128) * 2 == (cin + 63) / 64 && ((cout + 127) / 128) * 2 == (cout + 63) / 64;
     // ... and, padded, on the rectangular wide layers (384 <-> 192, 192 <-> 96: the strided levels' convs and the 2C -> C
@@ -497,7 +523,7 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
         }();
 #define SEG3D_LAUNCH_WIDE(XB_, D_)                                                                                             \
     hipLaunchKernelGGL((wgrad_sparse_wide_kernel<XB_, D_>), dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout, \
-                       (int)p.rows, nbi, tiles, units, part)
+                       (int)p.rows, nbi, tiles, units, part, center_first)
         if (x_bf16) {  // (two register sets of both row formats do not fit: 464 bytes of scratch at depth 2)
             SEG3D_LAUNCH_WIDE(true, 1);
         } else {
@@ -510,10 +536,10 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
         const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
         if (x_bf16)
             hipLaunchKernelGGL(wgrad_sparse_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
-                               (int)p.rows, p.nbi, tiles, units, part);
+                               (int)p.rows, p.nbi, tiles, units, part, center_first);
         else
             hipLaunchKernelGGL(wgrad_sparse_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
-                               (int)p.rows, p.nbi, tiles, units, part);
+                               (int)p.rows, p.nbi, tiles, units, part, center_first);
     }
     SEG3D_CHECK_LAUNCH();
     if (chunks_out) *chunks_out = p.chunks;

@@ -268,3 +268,52 @@ def test_linear_with_layernorm_epilogue(m, cin, cout):
         _lib.call("seg3d_linear_layernorm_fwd", ops._ptr(x), m, ops._ptr(ops._linear_pack(w2, 0)), ops._ptr(None), ops._ptr(None),
                   ops._ptr(torch.ones(384, device=dev)), ops._ptr(torch.zeros(384, device=dev)), 1e-5, cin, 384, ops._ptr(y),
                   ops._stream())
+
+
+@pytest.mark.parametrize("m,cin,cout", [(5000, 48, 48), (5003, 48, 96), (10007, 96, 48), (70001, 96, 96), (33333, 96, 192),
+                                        (121168, 192, 96), (58453, 192, 192), (58453, 192, 384), (4099, 192, 576), (15, 192, 192),
+                                        (1, 48, 144), (20000, 128, 96), (20000, 64, 48)])
+def test_row_streaming_linear_is_bit_identical_to_the_gather_gemm_case(m, cin, cout):
+    """(The schedule is OFF by default -- it lost the A/B, csrc/linear_stream.hip -- and is pinned here through the debug
+    switch so that the opt-in stays correct.)  Round 5's schedule of the dense Linear layers with cin <= 192 (csrc/linear_stream.hip: W block resident in LDS, every
+    wave streams its own 16-row tiles with a rolling prefetch, quad-transposed 16-byte stores) against the schedule it
+    replaces (the gather-GEMM's single-offset case, forced through the column-width switch): same products in the same order,
+    so the results agree BIT FOR BIT -- plain, with bias, with a residual addend and with the elementwise factor of fc2's
+    input gradient (seg3d_linear_fwd_mul) -- and both agree with fp64 within the split-bf16 tolerance."""
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(m * 7 + cin + cout)
+    x = torch.randn(m, cin, generator=gen).to(dev)
+    w = (torch.randn(cout, cin, generator=gen) / cin ** 0.5).to(dev)
+    b = torch.randn(cout, generator=gen).to(dev)
+    add = torch.randn(m, cout, generator=gen).to(dev)
+    packed = ops._linear_pack(w, False)
+    old_nbt = {48: 3, 96: 6, 144: 3, 192: 12, 384: 12, 576: 12}[cout]
+
+    def run(bias, addend, mul):
+        y = torch.full((m, cout), float("nan"), device=dev)
+        if mul:
+            _lib.call("seg3d_linear_fwd_mul", ops._ptr(x), m, ops._ptr(packed), ops._ptr(addend), cin, cout, ops._ptr(y), ops._stream())
+        else:
+            _lib.call("seg3d_linear_fwd", ops._ptr(x), m, ops._ptr(packed), ops._ptr(bias), ops._ptr(addend), cin, cout, ops._ptr(y),
+                      ops._stream())
+        return y
+
+    for bias, addend, mul in ((None, None, False), (b, None, False), (b, add, False), (None, add, True)):
+        _lib.call("seg3d_debug_set_linear_stream", 1)
+        try:
+            new = run(bias, addend, mul)
+        finally:
+            _lib.call("seg3d_debug_set_linear_stream", -1)  # back to the environment's choice
+        ops.debug_set_conv_nbt(old_nbt)  # a forced column width keeps the dense case on the gather-GEMM kernel
+        try:
+            old = run(bias, addend, mul)
+        finally:
+            ops.debug_set_conv_nbt(0)
+        assert torch.equal(new, old), (bias is not None, addend is not None, mul, float((new - old).abs().max()))
+        ref = x.double() @ w.double().t()
+        if bias is not None:
+            ref = ref + b.double()
+        if addend is not None:
+            ref = ref * add.double() if mul else ref + add.double()
+        assert float((new.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))

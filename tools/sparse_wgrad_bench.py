@@ -1,5 +1,6 @@
 """Per-layer timing of the sparse-conv weight gradients of one training step on the headline scene (through the C ABI):
 python tools/sparse_wgrad_bench.py"""
+import ctypes
 import os
 import sys
 
@@ -35,6 +36,10 @@ def main():
         m_out = nbr.shape[1]
         m_in = int(nbr.max().item()) + 1
         x = torch.randn(m_in, cin, device=dev)
+        xb = "--xbf16" in sys.argv  # the opt-in bf16 copies of the training mode: x rows as bf16, partial blocks only
+        if xb:
+            x = x.to(torch.bfloat16)
+        chunks = ctypes.c_int32(0)
         dy = torch.randn(m_out, cout, device=dev)
         dw = torch.empty(cout, 27, cin, device=dev)
         nb = _lib.query("seg3d_spconv_wgrad_workspace_bytes", m_out, cin, cout)
@@ -42,6 +47,10 @@ def main():
         pairs = int((nbr >= 0).sum().item())
 
         def run():
+            if xb or "--partials" in sys.argv:
+                _lib.call("seg3d_spconv_wgrad_partials_xbf16" if xb else "seg3d_spconv_wgrad_partials", ops._ptr(x), ops._ptr(dy),
+                          ops._ptr(nbr), m_out, m_in, cin, cout, ops._ptr(ws), nb, ctypes.byref(chunks), ops._stream())
+                return
             _lib.call("seg3d_spconv_wgrad", ops._ptr(x), ops._ptr(dy), ops._ptr(nbr), m_out, m_in, cin, cout, 4, ops._ptr(dw),
                       ops._ptr(ws), nb, ops._stream())
         for _ in range(3):

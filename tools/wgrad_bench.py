@@ -20,7 +20,14 @@ for m, cin, cout, calls in SHAPES:
     db = torch.empty(cout, device=dev)
     nb = _lib.query("seg3d_linear_wgrad_workspace_bytes", m, cin, cout)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    xb = "--xbf16" in sys.argv
+    xq = x.to(torch.bfloat16) if xb else x
+    chunks = ctypes.c_int32(0)
     def run():
+        if xb or "--partials" in sys.argv:
+            _lib.call("seg3d_linear_wgrad_partials_xbf16" if xb else "seg3d_linear_wgrad_partials", ops._ptr(xq), ops._ptr(dy), m, cin, cout,
+                      1, ops._ptr(ws), nb, ctypes.byref(chunks), ops._stream())
+            return
         _lib.call("seg3d_linear_wgrad", ops._ptr(x), ops._ptr(dy), m, cin, cout, ops._ptr(dw), ops._ptr(db), ops._ptr(ws), nb,
                   ops._stream())
     for _ in range(3):
