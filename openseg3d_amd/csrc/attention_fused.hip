@@ -595,7 +595,7 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
     const long long total = (long long)n_items * (heads / C::HG);
     static const int xcd_env = getenv("SEG3D_ATTN_XCD") ? atoi(getenv("SEG3D_ATTN_XCD")) : 8;  // A/B: 1 = flat order
     const int xg = xcd_env > 0 ? xcd_env : 8;
-    const int xb = xg == 1 ? 1 : xcd_block_items(C::kNarrow);
+    const int xb = xg == 1 ? 1 : xcd_block_items(C::kNarrow, n_items);
     long long wgs = total < (long long)n_cu * per_cu ? total : (long long)n_cu * per_cu;
     wgs = (wgs + xg - 1) / xg * xg;  // whole groups (a workgroup without units returns at once)
     const dim3 grid((unsigned)wgs);

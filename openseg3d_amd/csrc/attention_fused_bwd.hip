@@ -798,7 +798,7 @@ int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int
     using C = Cfg<DH>;
     const int2* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
-    const int xb = xcd_block_items(C::kNarrow);
+    const int xb = xcd_block_items(C::kNarrow, n_items);
     const dim3 grid((unsigned)(bwd_blocks(n_items, heads / C::HG, xb)));
     hipLaunchKernelGGL((attn_fused_bwd<DH, 0>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start,
                        win_count, items, n_items, heads, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, tau_part, delta_buf, drop, xb);
@@ -822,7 +822,7 @@ bool attn_fused_bwd_supported(int heads, int dh) {
 }
 
 static size_t tau_part_bytes(int n_tiles, int n_chunks, int heads, int dh) {
-    const size_t blocks = (dh <= 12) ? bwd_blocks(n_tiles, heads / 4, xcd_block_items(true)) : bwd_blocks(n_chunks, heads, xcd_block_items(false));
+    const size_t blocks = (dh <= 12) ? bwd_blocks(n_tiles, heads / 4, xcd_block_items(true, n_tiles)) : bwd_blocks(n_chunks, heads, xcd_block_items(false, n_chunks));
     return align_up(blocks * 4 * sizeof(float), 256);
 }
 

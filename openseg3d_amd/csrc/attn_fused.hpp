@@ -70,14 +70,18 @@ __host__ __device__ __forceinline__ int xcd_block_count(int n_items, int gx, int
     const int last = nb - 1;
     return mine * b - (last % xg == gx ? nb * b - n_items : 0);
 }
-// items per block: SEG3D_ATTN_XCD_BLOCK (A/B).  Default 1 = single items round-robin: measured on the headline scene,
-// forward + backward with dropout 8.35 - 8.40 ms at 1, 8.33 - 8.36 at 2 and 4 (within the run-to-run spread), 8.5 at 8 - 16,
-// 8.85 at 32 (whole windows on one XCD unbalance the groups; stage 4 with its 242 items loses 8 % already at 4).  The
-// kernels move 2 - 4.5 TB/s over the fabric and are not bound by it.
-inline int xcd_block_items(bool narrow) {
+// items per block: SEG3D_ATTN_XCD_BLOCK (A/B; > 0 forces one size for every kernel).  Default (round 5): 8 consecutive
+// 32-token tiles for the narrow heads (dh 6 / 12), 4 consecutive 128-token chunks for the wide heads -- measured on the
+// headline scene's forward (tools/r5_s6.sh, two --pmc passes per setting): fabric traffic per launch at block sizes 1 / 4 / 8:
+// dh 12 506 / 288 / 243 MB (footprint 186 MB: 2.7 x -> 1.3 x), dh 24 297 / 224 / 213, dh 48 185 / 140 / 135, dh 6 135 / 101 /
+// 95; forward of the 18 layers 1.554 / 1.498 / 1.511 ms.  (Round 3 had measured forward + backward a tie at 1 / 2 / 4 and
+// +2 % at 8 - 16 with ONE size for all kernels; whole windows on one XCD, 32, unbalance the groups: +6 %.)
+// Forward + backward with dropout of the 18 layers, same box, old (1 everywhere) against these defaults: 7.29 -> 7.24 ms, the
+// training step a tie (43.0 ms) -- the kernels are not bound by the fabric, the traffic is what falls.  Lists of fewer than
+// 512 chunks (stage 4: 242) keep single items: blocks of 4 leave 60 blocks for 8 XCDs and cost that stage 5 %.
+inline int xcd_block_items(bool narrow, int n_items) {
     static const int env = getenv("SEG3D_ATTN_XCD_BLOCK") ? atoi(getenv("SEG3D_ATTN_XCD_BLOCK")) : 0;
-    (void)narrow;
-    return env > 0 ? env : 1;
+    return env > 0 ? env : (narrow ? 8 : (n_items >= 512 ? 4 : 1));
 }
 
 }  // namespace attn_fused

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
                                                               const float* __restrict__ bias,
                                                               const void* __restrict__ addend_v,
                                                               const int32_t* __restrict__ row_order, int cin, int cout,
-                                                              void* __restrict__ y_v, int relu,
+                                                              void* __restrict__ y_v, int relu_flags,
                                                               const float* __restrict__ x_add, LnEpilogue ln) {
+    const int relu = relu_flags & 1;
     const float* __restrict__ x = static_cast<const float*>(x_v);
     const float* __restrict__ addend = static_cast<const float*>(addend_v);
     float* __restrict__ y = static_cast<float*>(y_v);
@@ -178,8 +179,32 @@ __global__ __launch_bounds__(256, 2) void spconv_split_kernel(const void* __rest
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
     const unsigned long long st_begin = st_last;
 #endif
-    const int64_t row0 = (int64_t)blockIdx.x * (kW * RB * 16) + wave * (RB * 16);
-    const int nb0 = blockIdx.y * NBT;
+    // relu_flags bit 1 (sparse tables, SEG3D_CONV_XCD_RUN): workgroup -> row tile so that each XCD (workgroup id % 8) walks ONE
+    // contiguous run of tiles -- neighbouring tiles gather overlapping parent rows, which then meet in one L2 instead of
+    // being fetched by eight (the grid is padded to a multiple of 8 tiles; surplus workgroups leave before any barrier)
+    int64_t tile_id = blockIdx.x;
+    int col_group = blockIdx.y;
+    if (relu_flags & 4) {
+        // relu_flags bit 2 (dense Linear layers with several column groups, 1-D grid): the column groups of ONE row tile are
+        // workgroups id, id + 8, id + 16, .. -- the same XCD, back to back -- so the row tile they all read crosses the fabric
+        // once and comes out of that XCD's L2 afterwards (a 2-D grid puts them gridDim.x workgroups apart, on any XCD)
+        const int ny = (cout >> 4) / NBT;
+        const int64_t n_tiles = (m_out + kW * RB * 16 - 1) / (kW * RB * 16);
+        const int64_t id = blockIdx.x;
+        const int64_t grp = id / (8 * ny);
+        const int t = (int)(id - grp * 8 * ny);
+        tile_id = grp * 8 + (t & 7);
+        col_group = t >> 3;
+        if (tile_id >= n_tiles) return;
+    }
+    if (relu_flags & 2) {
+        const int64_t n_tiles = (m_out + kW * RB * 16 - 1) / (kW * RB * 16);
+        const int64_t per = (n_tiles + 7) >> 3;
+        tile_id = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tile_id >= n_tiles) return;
+    }
+    const int64_t row0 = tile_id * (kW * RB * 16) + wave * (RB * 16);
+    const int nb0 = col_group * NBT;
     const int cb_n = (cin + 31) >> 5, nb_n = cout >> 4;
     const int64_t last_row = m_out - 1;
 
@@ -528,6 +553,25 @@ int launch_split(const void* x, const int32_t* nbr, int64_t m_out, const void* w
                  const int32_t* row_order, int cin, int cout, void* y, int relu, int io, hipStream_t st,
                  const float* x_add = nullptr, LnEpilogue ln = LnEpilogue{nullptr, nullptr, 0.f}) {
     dim3 grid((unsigned)ceil_div64(m_out, 4 * RB * 16), (unsigned)((cout / 16) / NBT));
+    // SEG3D_CONV_XCD_RUN (A/B, sparse tables only): every XCD walks one contiguous run of row tiles
+    static const int xcd_run = [] {
+        const char* e = getenv("SEG3D_CONV_XCD_RUN");
+        return (e && atoi(e) == 1) ? 1 : 0;
+    }();
+    if (xcd_run && nbr != nullptr && io == 0 && grid.x >= 64) {
+        grid.x = (grid.x + 7) / 8 * 8;
+        relu |= 2;
+    }
+    // SEG3D_LINEAR_COLGROUPS (A/B): 0 = the column groups of a dense Linear layer as the grid's y dimension (round 4)
+    static const int col_adjacent = [] {
+        const char* e = getenv("SEG3D_LINEAR_COLGROUPS");
+        return (e && atoi(e) == 0) ? 0 : 1;
+    }();
+    if (col_adjacent && nbr == nullptr && grid.y > 1 && (io == 0 || io == 3 || io == 4)) {
+        grid.x = (grid.x + 7) / 8 * 8 * grid.y;
+        grid.y = 1;
+        relu |= 4;
+    }
     if (io == 5) {  // Linear + LayerNorm + residual: the workgroup's columns must be the whole row
         if (nbr != nullptr || NBT * 16 != cout || !ln.gamma || !ln.beta) return SEG3D_EINVAL;
         hipLaunchKernelGGL((spconv_split_kernel<NBT, RB, true, 5>), grid, dim3(256), 0, st, x, nbr, m_out,

@@ -24,6 +24,27 @@
 
 int wgrad_chunk_reduce(const float* part, int chunks, int64_t n, int64_t nw, float* dw, float* db, hipStream_t st);
 
+#ifdef SEG3D_WGRAD_STAMP
+// In-kernel phase clocks of the wide kernel (tools/probes/wgrad_stamps.py; -DSEG3D_WGRAD_STAMP build only, never shipped):
+// per wave s_memtime sums of [0] pair compaction + its barriers, [1] ring reads + gather issue, [2] fragment reads + MFMAs,
+// [3] wait for the gathered rows + split + image store, [4] epilogue (store of the block), [5] steps, [6] whole wave.
+__device__ unsigned long long* g_wgrad_stamp_buf = nullptr;
+extern "C" int seg3d_debug_wgrad_stamps(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : 2;
+}
+#define WSTAMP(i)                                                    \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        st_acc[i] += t_ - st_last;                                   \
+        st_last = t_;                                                \
+    } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 using namespace attn;
@@ -108,10 +129,14 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const void* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cq = lane & 15, rg = lane >> 4;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int unit = (j / tiles) * 8 + xcd, tile = j % tiles;
+    // units are dealt to the XCDs in blocks of `xcd_block` consecutive units (center_first >> 8): the offsets of one row chunk
+    // gather the same dy rows and overlapping x rows -- on ONE L2 when they are neighbours in the block
+    const int xb = (center_first >> 8) > 0 ? (center_first >> 8) : 1;
+    const int qs = j / tiles, tile = j % tiles;
+    const int unit = ((qs / xb) * 8 + xcd) * xb + qs % xb;
     if (unit >= units) return;  // padding of the XCD-aligned grid (whole workgroup)
     int chunk = unit / 27, k = unit % 27;
-    if (center_first) unit_to_chunk_offset(unit, units / 27, &chunk, &k);
+    if (center_first & 1) unit_to_chunk_offset(unit, units / 27, &chunk, &k);
     const int bi = tile % nbi, bo = tile / nbi;
     const int ci0 = bi * 64, co0 = bo * 64;
     const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
@@ -291,10 +316,14 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
     const int cq = lane & 15, rg = lane >> 4;
     const int wa = wave >> 1, wb = wave & 1;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int unit = (j / tiles) * 8 + xcd, tile = j % tiles;
+    // units are dealt to the XCDs in blocks of `xcd_block` consecutive units (center_first >> 8): the offsets of one row chunk
+    // gather the same dy rows and overlapping x rows -- on ONE L2 when they are neighbours in the block
+    const int xb = (center_first >> 8) > 0 ? (center_first >> 8) : 1;
+    const int qs = j / tiles, tile = j % tiles;
+    const int unit = ((qs / xb) * 8 + xcd) * xb + qs % xb;
     if (unit >= units) return;  // padding of the XCD-aligned grid (whole workgroup)
     int chunk = unit / 27, k = unit % 27;
-    if (center_first) unit_to_chunk_offset(unit, units / 27, &chunk, &k);
+    if (center_first & 1) unit_to_chunk_offset(unit, units / 27, &chunk, &k);
     const int bi = tile % nbi, bo = tile / nbi;
     const int ci0 = bi * 128, co0 = bo * 128;
     const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
@@ -354,33 +383,48 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
 
     f32x4 raw[8], raw2[DEPTH == 2 ? 8 : 1];
     uint2 rawb[XB ? 8 : 1], rawb2[(XB && DEPTH == 2) ? 8 : 1];
+    // (the row format is a wave-uniform choice made ONCE per call, outside the gather loops: a branch per gathered row puts
+    // every load into a basic block of its own and the waits at the block boundaries serialise the eight gathers --
+    // measured: the bf16 variant ran 1.7 x SLOWER than the fp32 one that way)
     auto load_into = [&](f32x4* r, uint2* rb, int h0, int valid) {
+        int32_t rows[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = 8 * rg + i;
             const int2 p = ring[(h0 + (e < valid ? e : 0)) & (kRing2 - 1)];
-            if (XB && !stage_dy) {  // wave-uniform
-                if constexpr (XB) rb[i] = *reinterpret_cast<const uint2*>(srcb + (int64_t)p.x * ld);
-            } else {
-                r[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)(stage_dy ? p.y : p.x) * ld);
-            }
+            rows[i] = stage_dy ? p.y : p.x;
         }
-        if (valid < 32) {
+        if (XB && !stage_dy) {
+            if constexpr (XB) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (8 * rg + i >= valid) {
-                    r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if constexpr (XB) rb[i] = make_uint2(0u, 0u);
+                for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const uint2*>(srcb + (int64_t)rows[i] * ld);
+                if (valid < 32) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (8 * rg + i >= valid) rb[i] = make_uint2(0u, 0u);
                 }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)rows[i] * ld);
+            if (valid < 32) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (8 * rg + i >= valid) r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     auto stash_from = [&](const f32x4* r, const uint2* rb, int buf) {
+        if (XB && !stage_dy) {  // bf16 rows: the record is the row's own bits, there is no low plane
+            if constexpr (XB) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    img[buf][wave][0][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, frag_from_bf16_rows(rb, jj));
+            }
+            return;
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            if (XB && !stage_dy) {  // bf16 rows: the record is the row's own bits, there is no low plane
-                if constexpr (XB) img[buf][wave][0][rg][jj * 16 + cq] = __builtin_bit_cast(uint4, frag_from_bf16_rows(rb, jj));
-                continue;
-            }
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = r[i][jj];
@@ -412,6 +456,11 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
     };
 
     int buf = 0;
+#ifdef SEG3D_WGRAD_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
     if constexpr (DEPTH == 1) {
         refill();
         int valid = tail - head < 32 ? tail - head : 32;
@@ -419,15 +468,23 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
             load_slab(head, valid);
             stash(0);
         }
+        WSTAMP(7);
         while (valid > 0) {
             head += valid;
             refill();  // also the barrier that publishes image `buf`
+            WSTAMP(0);
             const int next = tail - head < 32 ? tail - head : 32;
             if (next > 0) load_slab(head, next);
+            WSTAMP(1);
             multiply(buf);
+            WSTAMP(2);
             if (next > 0) stash(buf ^ 1);
+            WSTAMP(3);
             buf ^= 1;
             valid = next;
+#ifdef SEG3D_WGRAD_STAMP
+            st_acc[5] += 1;
+#endif
         }
     } else {
         // Two steps of gathers in flight: the rows of step s+2 are requested before the MFMAs of step s and converted after
@@ -476,6 +533,18 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
             *reinterpret_cast<f32x4*>(pw + ((int64_t)co * 27 + k) * cin + ci) =
                 *reinterpret_cast<const f32x4*>(&st[row * 64 + 4 * q]);
     }
+#ifdef SEG3D_WGRAD_STAMP
+    if constexpr (DEPTH == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WSTAMP(4);
+        if (g_wgrad_stamp_buf && lane == 0) {
+            st_acc[6] = __builtin_amdgcn_s_memtime() - st_begin;
+            unsigned long long* o = g_wgrad_stamp_buf + (k == 13 ? 8 : 0);  // centre units apart from the rest
+            for (int i = 0; i < 8; ++i) atomicAdd(o + i, st_acc[i]);
+            atomicAdd(g_wgrad_stamp_buf + 16 + (k == 13 ? 1 : 0), 1ull);  // waves counted
+        }
+    }
+#endif
 }
 
 }  // namespace
@@ -497,8 +566,15 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
     // SEG3D_WGRAD_CENTER_FIRST (A/B): 0 = units in (chunk, offset) order (round 4)
     static const int center_first = [] {
         const char* e = getenv("SEG3D_WGRAD_CENTER_FIRST");
-        return (e && atoi(e) == 0) ? 0 : 1;
+        const int cf = (e && atoi(e) == 0) ? 0 : 1;
+        // SEG3D_WGRAD_XCD_BLOCK (A/B): consecutive units per XCD (1 = round-robin, round 4's order)
+        const char* b = getenv("SEG3D_WGRAD_XCD_BLOCK");
+        int xb = b ? atoi(b) : 1;
+        if (xb < 1 || xb > 64) xb = 1;
+        return cf | (xb << 8);
     }();
+    const int xcd_block = center_first >> 8;
+    const int unit_slots = (units + 8 * xcd_block - 1) / (8 * xcd_block) * (8 * xcd_block);  // grid padding: whole blocks on every XCD
     // 128-wide blocks only where they add no padding (C = 256, 384, 768; not 192 = 1.5 blocks)
     const bool fits128 = ((cin + 127) / 128) * 2 == (cin + 63) / 64 && ((cout + 127) / 128) * 2 == (cout + 63) / 64;
     // ... and, padded, on the rectangular wide layers (384 <-> 192, 192 <-> 96: the strided levels' convs and the 2C -> C
@@ -514,7 +590,7 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
     const bool wide_padded = (wide_min > 0 && cmin >= wide_min) || (cin != cout && cmin >= 96 && cmax >= 192);
     if ((fits128 || wide_padded) && !narrow_only) {
         const int nbo = (cout + 127) / 128, nbi = (cin + 127) / 128, tiles = nbo * nbi;
-        const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
+        const unsigned blocks = (unsigned)unit_slots * (unsigned)tiles;
         // SEG3D_WGRAD_DEPTH (A/B): gather steps in flight per wave (1 or 2)
         static const int depth = [] {
             const char* e = getenv("SEG3D_WGRAD_DEPTH");
@@ -533,7 +609,7 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
 #undef SEG3D_LAUNCH_WIDE
     } else {
         const int tiles = p.nbo * p.nbi;
-        const unsigned blocks = (unsigned)((units + 7) / 8 * 8) * (unsigned)tiles;
+        const unsigned blocks = (unsigned)unit_slots * (unsigned)tiles;
         if (x_bf16)
             hipLaunchKernelGGL(wgrad_sparse_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout,
                                (int)p.rows, p.nbi, tiles, units, part, center_first);

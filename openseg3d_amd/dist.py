@@ -220,6 +220,12 @@ class SceneParallel(torch.nn.Module):
         for p in self._params:
             ops.DEFER_OWNED.discard(p)
 
+    def __del__(self):  # a wrapper that is dropped gives its parameters back to the by-construction rule
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _self_test(self):
         """The collective pattern of reduce_gradients on the live group, before a gradient depends on it: slices of one flat
         tensor, asynchronous, averaged (or summed and divided)."""
