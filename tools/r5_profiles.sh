@@ -1,4 +1,5 @@
 set -x
+export SEG3D_BENCH_IDLE_PROBE=0  # the idle probe (device-side sleeps, extra steps) must not enter the step cut of the trace
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5p
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5p/fwd -- python3 bench.py --mode fwd --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-exact > gpurun_out/r5p/fwd.json 2> gpurun_out/r5p/fwd.err && \
