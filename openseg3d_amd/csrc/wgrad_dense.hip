@@ -34,11 +34,46 @@ struct Plan {
     int nbo, nbi;  // 64-channel blocks along cout / cin
     int chunks;    // row chunks (partial sums)
     int64_t rows;  // rows per chunk (multiple of 32)
+    int group;     // 0 = the waves of a workgroup split the rows of one block; else QB << 4 | QC blocks per workgroup
 };
 
+// SEG3D_WGRAD_GROUP=1 (A/B, OFF by default: it lost).  Measured (tools/wgrad_bench.py, one box, split-K -> groups): 96 -> 192
+// @121 k rows 36.7 -> 45.9 us, 96 -> 96 29.2 -> 37.6, 192 -> 384 @58 k 52.3 -> 55.6, 192 -> 192 32.2 -> 35.1; only the 19 k-row
+// level gains (384 -> 768 70.4 -> 63.7, 384 -> 384 39.6 -> 35.9); training step 42.3 -> 42.7 ms.  The waves of a group drift
+// apart by more rows than the 32 KB L1 holds, so the shared slab is fetched from L2 by each of them anyway, and a wave's chain
+// is four times as long.
+static const bool g_wgrad_group = [] {
+    const char* e = getenv("SEG3D_WGRAD_GROUP");
+    return e && atoi(e) == 1;
+}();
+
 Plan plan(int64_t m, int cin, int cout) {
-    Plan p{(cout + 63) / 64, (cin + 63) / 64, 0, 32};
+    Plan p{(cout + 63) / 64, (cin + 63) / 64, 0, 32, 0};
     if (m <= 0) return p;
+    if (g_wgrad_group && p.nbo * p.nbi >= 4 && m >= 8192) {
+        // the block group with the fewest operand slabs per block among the shapes that divide the block grid; at least three waves
+        int best_b = 0, best_c = 0;
+        float best = 1e9f;
+        for (int qb = 1; qb <= 4; ++qb)
+            for (int qc = 1; qb * qc <= 4; ++qc) {
+                if (p.nbo % qb || p.nbi % qc || qb * qc < 3) continue;
+                const float slabs = (float)(qb + qc) / (float)(qb * qc) - 0.01f * (float)(qb * qc);
+                if (slabs < best) best = slabs, best_b = qb, best_c = qc;
+            }
+        if (best_b) {
+            p.group = best_b << 4 | best_c;
+            const int groups = (p.nbo / best_b) * (p.nbi / best_c);
+            // one resident round of workgroups (512), every wave walking its whole chunk: >= 8 steps per wave
+            int64_t chunks = 512 / groups / 8 * 8;
+            if (chunks < 8) chunks = 8;
+            int64_t rows = (m + chunks - 1) / chunks;
+            if (rows < 32 * 8) rows = 32 * 8;
+            rows = (rows + 31) / 32 * 32;
+            p.rows = rows;
+            p.chunks = (int)((m + rows - 1) / rows);
+            return p;
+        }
+    }
     const int tiles = p.nbo * p.nbi;
     // 2 waves per SIMD = 2 workgroups per CU = 512 resident workgroups.  Few blocks per chunk: one resident
     // round of long chunks (per-workgroup prologue / reduction overhead matters); many blocks per chunk: two
@@ -75,19 +110,32 @@ __device__ __forceinline__ f32x4 mfma2(const bf16x8& a_hi, const bf16x8& a_lo, c
 
 // XB: the x rows are stored as bf16 (the opt-in bf16 copies a training forward saves for its backward, SEG3D_TRAIN_STORAGE=bf16):
 // 8-byte loads, no split of x, two MFMAs per product.  dy is always fp32.
-template <bool XB>
+// GROUP (round 5): instead of splitting the ROWS of a chunk over the workgroup's waves (all on ONE 64 x 64 block, summed
+// through LDS at the end), the waves take NEIGHBOURING blocks -- QB x QC of them (group = QB << 4 | QC, <= 4 waves) -- and every
+// wave walks all rows of the chunk: the dy slab is read by QC waves and the x slab by QB waves at about the same time, so
+// the second reader finds it in the CU's L1 and the L2 -> L1 stream that bounds this kernel falls by a third to a half
+// (192 <-> 384: 18 blocks x 128 channel-reads per row = 2 304 -> 6 groups x 256 = 1 536).  No cross-wave sum, no barrier: a wave
+// stores its own block.  Per-wave work is 4 x longer, so the chunks are 2 x shorter (the partial blocks double: still a
+// quarter of the operand bytes).
+template <bool XB, bool GROUP>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                int64_t m_rows, int cin, int cout, int rows_per_chunk,
                                                                int nbi, int tiles, float* __restrict__ part,
-                                                               int want_bias) {
+                                                               int want_bias, int group) {
     const float* x = static_cast<const float*>(x_v);
-    __shared__ __attribute__((aligned(16))) float red[64 * 64];  // block sum [co_local][ci_local]
-    __shared__ float red_b[kWaves][64];
+    __shared__ __attribute__((aligned(16))) float red[GROUP ? 4 : 64 * 64];  // block sum [co_local][ci_local]
+    __shared__ float red_b[GROUP ? 1 : kWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cq = lane & 15, rg = lane >> 4;  // channel quad, row group: load role == MFMA role (c16, g)
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int chunk = (k / tiles) * 8 + xcd, tile = k % tiles;
-    const int bi = tile % nbi, bo = tile / nbi;
+    int bi = tile % nbi, bo = tile / nbi;  // GROUP: `tiles` counts groups and nbi groups along cin
+    if constexpr (GROUP) {
+        const int qb = group >> 4, qc = group & 15;
+        if (wave >= qb * qc) return;  // (a group of 2 or 3 blocks leaves wave slots empty; nothing below synchronises the workgroup)
+        bo = bo * qb + wave / qc;
+        bi = bi * qc + wave % qc;
+    }
     const int ci0 = bi * 64, co0 = bo * 64;
     const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
     if (r_begin >= m_rows) return;  // padding of the XCD-aligned grid (whole workgroup)
@@ -160,20 +208,21 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
     // full 32-row steps: the x rows of the wave's next step are requested as soon as this step's are converted,
     // its dy rows right after their last use
     const int n_full = (int)((r_end - r_begin) / 32);
-    int s = wave;
+    constexpr int kStride = GROUP ? 1 : kWaves;  // GROUP: every wave walks all steps of the chunk
+    int s = GROUP ? 0 : wave;
     if (s < n_full) {
         load_x(s);
         load_rows(dy, cout, yoff, s, yr);
     }
-    for (; s < n_full; s += kWaves) {
-        const bool more = s + kWaves < n_full;
+    for (; s < n_full; s += kStride) {
+        const bool more = s + kStride < n_full;
         make_b();
-        if (more) load_x(s + kWaves);
+        if (more) load_x(s + kStride);
         multiply();
-        if (more) load_rows(dy, cout, yoff, s + kWaves, yr);
+        if (more) load_rows(dy, cout, yoff, s + kStride, yr);
     }
     // the chunk's last, partial step (only the last chunk of the tensor has one): rows clamped and masked
-    if ((r_end - r_begin) % 32 != 0 && n_full % kWaves == wave) {
+    if ((r_end - r_begin) % 32 != 0 && (GROUP || n_full % kWaves == wave)) {
         const int64_t r0 = r_begin + 32 * (int64_t)n_full + 8 * rg;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -194,6 +243,28 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
         multiply();
     }
 
+    float* pw = part + (int64_t)chunk * ((int64_t)cout * cin + cout);
+    if constexpr (GROUP) {
+        // a wave stores its own block straight from the accumulators: acc[a][b][r] = dw[co = 4*(4g + r) + a][ci = 4*c16 + b]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + 4 * (4 * rg + r) + a, ci = ci0 + 4 * cq;
+                if (co < cout && ci < cin)
+                    *reinterpret_cast<f32x4*>(pw + (int64_t)co * cin + ci) = (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+            }
+        if (want_db) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = db_acc[j];
+                v += __shfl_xor(v, 16, SEG3D_WAVE);
+                v += __shfl_xor(v, 32, SEG3D_WAVE);
+                if (rg == 0 && co0 + 4 * cq + j < cout) pw[(int64_t)cout * cin + co0 + 4 * cq + j] = v;
+            }
+        }
+        return;
+    }
     // ---- sum the waves' blocks in wave order: acc[a][b][r] = dw[co = 4*(4g + r) + a][ci = 4*c16 + b]
     for (int w = 0; w < kWaves; ++w) {
         if (wave == w) {
@@ -210,7 +281,6 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
         __syncthreads();
     }
     // partial of this chunk: [cout][cin] block sums followed by [cout] column sums of dy
-    float* pw = part + (int64_t)chunk * ((int64_t)cout * cin + cout);
     for (int e = threadIdx.x; e < 64 * 16; e += kThreads) {
         const int row = e >> 4, q = e & 15;
         const int co = co0 + row, ci = ci0 + 4 * q;
@@ -325,6 +395,31 @@ extern "C" size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int
 
 // The two halves of seg3d_linear_wgrad apart: partial blocks now, their fixed-order sum later (alone, or batched with the
 // other pending sums of a backward pass).  *chunks receives the number of partial blocks written (0 when m == 0).
+// one launch of the partial-block kernel for plan p
+static void launch_dense(const Plan& p, const void* x, bool x_bf16, const float* dy, int64_t m, int cin, int cout, float* part,
+                         int want_bias, hipStream_t st) {
+    if (p.group) {
+        const int qb = p.group >> 4, qc = p.group & 15;
+        const int nbi_g = p.nbi / qc, groups = (p.nbo / qb) * nbi_g;
+        const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)groups;
+        if (x_bf16)
+            hipLaunchKernelGGL((wgrad_dense_kernel<true, true>), dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows,
+                               nbi_g, groups, part, want_bias, p.group);
+        else
+            hipLaunchKernelGGL((wgrad_dense_kernel<false, true>), dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows,
+                               nbi_g, groups, part, want_bias, p.group);
+        return;
+    }
+    const int tiles = p.nbo * p.nbi;
+    const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
+    if (x_bf16)
+        hipLaunchKernelGGL((wgrad_dense_kernel<true, false>), dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows,
+                           p.nbi, tiles, part, want_bias, 0);
+    else
+        hipLaunchKernelGGL((wgrad_dense_kernel<false, false>), dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows,
+                           p.nbi, tiles, part, want_bias, 0);
+}
+
 static int linear_wgrad_partials(const void* x, bool x_bf16, const float* dy, int64_t m, int32_t cin, int32_t cout,
                                  int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks, void* stream) {
     if (m < 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || !chunks) return SEG3D_EINVAL;
@@ -333,14 +428,7 @@ static int linear_wgrad_partials(const void* x, bool x_bf16, const float* dy, in
     *chunks = 0;
     if (m == 0) return SEG3D_OK;
     const Plan p = plan(m, cin, cout);
-    const int tiles = p.nbo * p.nbi;
-    const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
-    if (x_bf16)
-        hipLaunchKernelGGL(wgrad_dense_kernel<true>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), x, dy, m, cin, cout,
-                           (int)p.rows, p.nbi, tiles, static_cast<float*>(workspace), with_bias ? 1 : 0);
-    else
-        hipLaunchKernelGGL(wgrad_dense_kernel<false>, dim3(blocks), dim3(kThreads), 0, as_stream(stream), x, dy, m, cin, cout,
-                           (int)p.rows, p.nbi, tiles, static_cast<float*>(workspace), with_bias ? 1 : 0);
+    launch_dense(p, x, x_bf16, dy, m, cin, cout, static_cast<float*>(workspace), with_bias ? 1 : 0, as_stream(stream));
     SEG3D_CHECK_LAUNCH();
     *chunks = p.chunks;
     return SEG3D_OK;
@@ -382,10 +470,7 @@ extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, in
     const Plan p = plan(m, cin, cout);
     float* part = static_cast<float*>(workspace);
     if (m > 0) {
-        const int tiles = p.nbo * p.nbi;
-        const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
-        hipLaunchKernelGGL(wgrad_dense_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows, p.nbi,
-                           tiles, part, db ? 1 : 0);
+        launch_dense(p, x, false, dy, m, cin, cout, part, db ? 1 : 0, st);
         SEG3D_CHECK_LAUNCH();
     }
     // without db the trailing [cout] columns of each partial are never written; their sums are discarded
