@@ -302,14 +302,17 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_kernel(const void* _
 // s+1 are issued before the MFMAs of step s.
 constexpr int kRing2 = 512;  // pairs: at most 31 left over + 256 new
 
-template <bool XB, int DEPTH>
-__global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
+// SB (round 5 experiment): ONE image buffer instead of two and three workgroups per CU instead of two -- a second barrier per
+// step (all waves must have read the image before the next step's rows overwrite it) against half more resident waves to
+// hide the gathers' round trips behind (the stamps say 44 % of a step is waiting for rows).
+template <bool XB, int DEPTH, bool SB = false>
+__global__ __launch_bounds__(kThreads, SB ? 3 : 2) void wgrad_sparse_wide_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                          const int32_t* __restrict__ nbr, int64_t m_rows,
                                                                          int cin, int cout, int rows_per_chunk, int nbi,
                                                                          int tiles, int units, float* __restrict__ part,
                                                                          int center_first) {
     const float* x = static_cast<const float*>(x_v);
-    __shared__ __attribute__((aligned(16))) uint4 img[2][4][2][4][64];  // [buffer][slab][hi|lo][row group][record] 64 KiB
+    __shared__ __attribute__((aligned(16))) uint4 img[SB ? 1 : 2][4][2][4][64];  // [buffer][slab][hi|lo][row group][record] 64 KiB
     __shared__ int2 ring[kRing2];
     __shared__ int wave_cnt[2][kWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -478,9 +481,14 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
             WSTAMP(1);
             multiply(buf);
             WSTAMP(2);
-            if (next > 0) stash(buf ^ 1);
+            if constexpr (SB) {
+                __syncthreads();  // every wave has read the image: the next step's rows may overwrite it
+                if (next > 0) stash(0);
+            } else {
+                if (next > 0) stash(buf ^ 1);
+                buf ^= 1;
+            }
             WSTAMP(3);
-            buf ^= 1;
             valid = next;
 #ifdef SEG3D_WGRAD_STAMP
             st_acc[5] += 1;
@@ -517,6 +525,19 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_sparse_wide_kernel(const vo
     __syncthreads();  // all reads of the images done: reuse them as the store staging area
 
     // ---- store: acc[a][b][r] = dw[co = 4*(4g + r) + a][ci = 4*c16 + b] of this wave's 64 x 64 sub-block
+    if constexpr (SB) {  // (the single image is too small to stage four blocks: 16-byte stores straight from the accumulators)
+        float* pw = part + (int64_t)chunk * ((int64_t)cout * 27 * cin);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + 64 * wa + 4 * (4 * rg + r) + a, ci = ci0 + 64 * wb + 4 * cq;
+                if (co < cout && ci < cin)
+                    *reinterpret_cast<f32x4*>(pw + ((int64_t)co * 27 + k) * cin + ci) =
+                        (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+            }
+        return;
+    }
     float* st = reinterpret_cast<float*>(&img[0][0][0][0][0]) + wave * 4096;  // 16 KiB per wave
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -600,12 +621,27 @@ int wgrad_split_sparse(const void* x, const float* dy, const int32_t* nbr, int64
 #define SEG3D_LAUNCH_WIDE(XB_, D_)                                                                                             \
     hipLaunchKernelGGL((wgrad_sparse_wide_kernel<XB_, D_>), dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout, \
                        (int)p.rows, nbi, tiles, units, part, center_first)
-        if (x_bf16) {  // (two register sets of both row formats do not fit: 464 bytes of scratch at depth 2)
+        // SEG3D_WGRAD_SB (A/B): 0 = round 4's double-buffered image at two workgroups per CU.  Default 1 (round 5): ONE image
+        // buffer (37 KB of LDS, 162 VGPRs) and THREE workgroups per CU -- the kernel waits for gathered rows 44 % of the time, and
+        // half more resident waves hide more of it than the second barrier per step costs: the 11 wide layers of the headline
+        // step 4.95 -> 4.76 ms alone (inverse tables -11 %, 768 -> 384 -6 %), training step 42.95 -> 42.77 ms, same bits.
+        static const bool single = [] {
+            const char* e = getenv("SEG3D_WGRAD_SB");
+            return !(e && atoi(e) == 0);
+        }();
+#define SEG3D_LAUNCH_WIDE_SB(XB_)                                                                                                   \
+    hipLaunchKernelGGL((wgrad_sparse_wide_kernel<XB_, 1, true>), dim3(blocks), dim3(kThreads), 0, st, x, dy, nbr, m_out, cin, cout, \
+                       (int)p.rows, nbi, tiles, units, part, center_first)
+        if (single && depth == 1) {
+            if (x_bf16) SEG3D_LAUNCH_WIDE_SB(true);
+            else SEG3D_LAUNCH_WIDE_SB(false);
+        } else if (x_bf16) {  // (two register sets of both row formats do not fit: 464 bytes of scratch at depth 2)
             SEG3D_LAUNCH_WIDE(true, 1);
         } else {
             if (depth == 2) SEG3D_LAUNCH_WIDE(false, 2);
             else SEG3D_LAUNCH_WIDE(false, 1);
         }
+#undef SEG3D_LAUNCH_WIDE_SB
 #undef SEG3D_LAUNCH_WIDE
     } else {
         const int tiles = p.nbo * p.nbi;
