@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (6290 GB/s measured copy), MI355X_MICROARCH.md:36
 MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md:43
-PMC_TRAFFIC_FILES = ("r04_pmc_conv_traffic.json", "r04_pmc_conv_traffic_dense2m.json", "r04_pmc_conv_traffic_cylinder.json",
+PMC_TRAFFIC_FILES = ("r05_pmc_conv_traffic.json", "r05_pmc_conv_traffic_dense2m.json", "r05_pmc_conv_traffic_cylinder.json",
+                     "r05_pmc_conv_traffic_multi_sweeps.json", "r05_pmc_conv_traffic_spnet.json", "r04_pmc_conv_traffic.json", "r04_pmc_conv_traffic_dense2m.json", "r04_pmc_conv_traffic_cylinder.json",
                      "r04_pmc_conv_traffic_multi_sweeps.json", "r04_pmc_conv_traffic_spnet.json", "r03_pmc_conv_traffic.json", "r03_pmc_conv_traffic_dense2m.json", "r03_pmc_conv_traffic_cylinder.json",
                      "r03_pmc_conv_traffic_multi_sweeps.json", "r03_pmc_conv_traffic_spnet.json", "r02_pmc_conv_traffic.json")
 ATTENTION_REPORT = None  # filled by conv_roofline's instrumented forward
@@ -584,8 +585,10 @@ def main():
             e0 = ev()
             opt.zero_grad(set_to_none=True)
             res = net(b)
+            ef = ev()
             data = {"point_labels": labels[j], "voxel_labels": voxel_labels[j], "batch_size": b["batch_size"]}
             loss = _losses.compute_loss(res, data, criterion, cfg)
+            el = ev()
             loss.backward()
             h1 = time.perf_counter()
             e1 = ev()
@@ -594,7 +597,7 @@ def main():
             e2 = ev()
             prefetch(i)
             h3 = time.perf_counter()
-            rec.append((e0, e1, e2, h0, h1, h2, h3))
+            rec.append((e0, e1, e2, h0, h1, h2, h3, ef, el))
 
         steady, fed = [], []
         for i in range(k + 1):
@@ -618,6 +621,9 @@ def main():
                 "gpu_opt_step_ms_fed": round(mean([ms(r[1], r[2]) for r in fed]), 3),
                 "gpu_between_steps_ms": round(mean([ms(steady[i][2], steady[i + 1][0]) for i in range(k)]), 3),
                 "gpu_idle_ms": round(max(steady_step - fed_step, 0.0), 3),
+                # where the steady step is longer than the fed one: forward / criterion / backward segments of the main stream
+                "gpu_segments_ms_steady": [round(mean([ms(r[a], r[b]) for r in steady[:k]]), 3) for a, b in ((0, 7), (7, 8), (8, 1))],
+                "gpu_segments_ms_fed": [round(mean([ms(r[a], r[b]) for r in fed]), 3) for a, b in ((0, 7), (7, 8), (8, 1))],
                 "note": "HIP events on the main stream, no profiler: steady = consecutive steps as timed; fed = each step enqueued "
                         "whole behind a 50 ms device-side sleep (the host cannot be late); gpu_idle_ms = steady - fed per step; "
                         "gpu_opt_step_ms = backward's last kernel to the fused SGD's last (the profiled timeline shows a 2.1 ms "

@@ -111,7 +111,9 @@ class _PassEnd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         owner = ctx.owner
-        if owner._sync and not owner._queued:
+        # (the node exists only for a forward made with synchronisation on: like DistributedDataParallel, what counts is the
+        # state at FORWARD time -- a backward() issued inside no_sync() for such a forward still exchanges)
+        if not owner._queued:
             owner._begin_pass()
             torch.autograd.Variable._execution_engine.queue_callback(owner._after_backward)
         return (None,) + grads
