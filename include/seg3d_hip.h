@@ -303,6 +303,18 @@ int seg3d_linear_pack_weight_f32(const float* weight, int32_t cin, int32_t cout,
                                  void* w_packed, void* stream);
 int seg3d_linear_fwd_f32(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
                          int32_t cin, int32_t cout, float* y, void* stream);
+/* a6  fp32-GRADE variant on the bf16 matrix pipe (round 5; the default of the per-point MLPs, segformer.py:21-32,58-76):
+ * every operand split three ways (x = h + m + l, bf16 each: exact), six v_mfma_f32_16x16x32_bf16 per product keep every
+ * term down to 2^-16 of the leading one, the dropped ones are <= 2^-24 -- the error of an fp32 sum, at 6/16 of the fp32
+ * MFMA's time (openseg3d_amd/csrc/linear_x6.hip).  cin a multiple of 32, cout of 64 (packed_bytes = 0 otherwise: the
+ * caller takes seg3d_linear_fwd_f32).  Optional epilogue y * scale[col] + shift[col] (both or neither) and ReLU: the eval
+ * form of the BatchNorm1d + ReLU behind these layers (seg3d/models/segmentors/segformer.py:21-32). */
+size_t seg3d_linear_packed_bytes_x6(int32_t cin, int32_t cout);
+int seg3d_linear_pack_weight_x6(const float* weight, int32_t cin, int32_t cout, int32_t transpose, void* w_packed,
+                                void* stream);
+int seg3d_linear_fwd_x6(const float* x, int64_t m, const void* w_packed, const float* bias /*or NULL*/,
+                        const float* scale /*or NULL*/, const float* shift /*or NULL*/, int32_t relu, int32_t cin,
+                        int32_t cout, float* y, void* stream);
 
 /* Batched split-bf16 packing: one launch for every conv / Linear weight whose pack is stale (in training all of
  * them, twice: W for forward, W^T for the input gradient).  `jobs` is a DEVICE array of n_jobs records sorted by

@@ -1023,6 +1023,37 @@ def _linear_apply_f32(x, packed, bias, cin, cout):
     return y
 
 
+# Arithmetic of the per-point MLPs' forward ("exact" Linear layers): "x6" = three-way bf16 split, six bf16 MFMAs per product,
+# fp32-grade results at 6/16 of the fp32 MFMA's time (csrc/linear_x6.hip; shapes with cin % 32 == 0 and cout % 64 == 0);
+# "fp32" = v_mfma_f32_16x16x4_f32 everywhere (rounds 1 - 4; also what SEG3D_CONV_PRECISION=fp32 selects).
+POINT_MLP = os.environ.get("SEG3D_POINT_MLP", "x6")
+
+
+def _x6_fits(cin, cout):
+    return POINT_MLP == "x6" and CONV_PRECISION == "bf16x3" and cin % 32 == 0 and cout % 64 == 0
+
+
+def _linear_pack_x6(weight):
+    """Three-plane bf16 fragment stream of a Linear weight, cached on the parameter while its version is unchanged."""
+    cache = weight.__dict__.setdefault("_seg3d_x6_packs", {})
+    hit = cache.get(0)
+    if hit is not None and hit[0] == (_stamp(weight), weight.data_ptr()):
+        return hit[1]
+    w = _f32c(weight)
+    cout, cin = w.shape
+    out = torch.empty((_lib.query("seg3d_linear_packed_bytes_x6", cin, cout),), dtype=torch.uint8, device=w.device)
+    _lib.call("seg3d_linear_pack_weight_x6", _ptr(w), cin, cout, 0, _ptr(out), _stream())
+    cache[0] = ((_stamp(weight), weight.data_ptr()), out)
+    return out
+
+
+def _linear_apply_x6(x, packed, bias, cin, cout, scale=None, shift=None, relu=False):
+    y = torch.empty((x.shape[0], cout), dtype=torch.float32, device=x.device)
+    _lib.call("seg3d_linear_fwd_x6", _ptr(x), x.shape[0], _ptr(packed), _ptr(bias), _ptr(scale), _ptr(shift), int(relu),
+              cin, cout, _ptr(y), _stream())
+    return y
+
+
 LINEAR_LN_FUSED = os.environ.get("SEG3D_LINEAR_LN", "1") != "0"  # 0 = inference encoder layers run Linear and LayerNorm apart
 
 
@@ -1051,7 +1082,9 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(_saved_rows(x) if ctx.needs_input_grad[1] else x, weight)
         ctx.has_bias, ctx.exact = bias is not None, exact
         ctx.bias_param = bias  # (a reference for the deferred-join bookkeeping of the weight-gradient stream)
-        if exact:  # exact-fp32 MFMA kernel (rocBLAS for odd shapes); only the weight gradient uses the split kernel
+        if exact:  # fp32-grade forward (six-product split, or the fp32 MFMA; rocBLAS for odd shapes); the gradients use the split kernels
+            if _x6_fits(cin, cout):
+                return _linear_apply_x6(x, _linear_pack_x6(weight), None if bias is None else _f32c(bias), cin, cout)
             if cin % 16 == 0 and cout % 16 == 0:
                 return _linear_apply_f32(x, _linear_pack_f32(weight, 0), None if bias is None else _f32c(bias), cin, cout)
             return torch.nn.functional.linear(x, weight, bias)
@@ -1132,10 +1165,11 @@ class _LinearOddShapeFn(torch.autograd.Function):
 def linear(x, weight, bias=None, exact=False):
     """F.linear for [rows, C] activations.  Layers whose shape fits the MFMA tiles (cin % 8 == 0,
     cout % 16 == 0) run in libseg3d_hip.so in split-bf16 arithmetic; the rest (6 -> 64 input layer, -> 22
-    classifiers) stay on rocBLAS.  ``exact=True`` keeps forward and input gradient in exact fp32 (v_mfma_f32_16x16x4_f32
-    kernel, rocBLAS for shapes it does not take) and only takes the weight gradient from the split kernel: used by the per-point MLPs, whose ~2^-16 relative forward
-    error would land directly on the O(25) logits (measured 1e-3 absolute) instead of being washed out by the
-    LayerNorms of the voxel path."""
+    classifiers) stay on rocBLAS.  ``exact=True`` keeps the FORWARD at fp32 grade -- the six-product three-way split of
+    csrc/linear_x6.hip (``SEG3D_POINT_MLP=x6``, default, cin % 32 == 0 and cout % 64 == 0), else the v_mfma_f32_16x16x4_f32
+    kernel, rocBLAS for shapes neither takes -- and takes the gradients from the split kernels: used by the per-point MLPs,
+    whose ~2^-16 relative forward error would land directly on the logits (measured 1e-3 absolute) instead of being
+    washed out by the LayerNorms of the voxel path."""
     fits = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 16 == 0
             and weight.shape[1] % 8 == 0 and CONV_PRECISION == "bf16x3")
     if exact and fits and weight.shape[1] % 16 == 0:
@@ -1497,6 +1531,24 @@ def batch_norm_act(x, bn, relu=True, res=None):
         _lib.call("seg3d_affine_act", _ptr(xc), _ptr(r), _ptr(scale), _ptr(shift), int(relu), xc.shape[0], c, _ptr(y),
                   _stream())
     return y
+
+
+def linear_bn_act_eval(x, lin, bn, relu):
+    """act(bn(lin(x))) in ONE launch for the eval forward of the per-point MLPs (Linear -> BatchNorm1d -> ReLU,
+    seg3d/models/segmentors/segformer.py:21-32): the six-product Linear kernel applies the BatchNorm's folded affine and the
+    ReLU in its epilogue, rounding as the separate seg3d_affine_act pass does (bit-identical to linear + batch_norm_act).
+    Returns None when the shapes / modes are not this path's (the caller runs the two passes)."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+        return None
+    cout, cin = lin.weight.shape
+    if not _x6_fits(cin, cout) or bn.training or not bn.track_running_stats or not bn.affine or bn.num_features != cout:
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
+        return None
+    with torch.no_grad():
+        scale, shift, _ = bn_eval_affine(bn)
+        return _linear_apply_x6(_f32c(x), _linear_pack_x6(lin.weight), None if lin.bias is None else _f32c(lin.bias), cin, cout,
+                                scale=scale, shift=shift, relu=relu)
 
 
 # ------------------------------------------------------------------------------------------ a13-a18 windows

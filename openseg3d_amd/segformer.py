@@ -68,6 +68,15 @@ class FusedMLP(nn.Sequential):
         i = 0
         while i < len(mods):
             m = mods[i]
+            # eval: Linear -> BatchNorm1d (-> ReLU) as one launch (the BatchNorm's folded affine in the Linear's epilogue)
+            if isinstance(m, RowLinear) and i + 1 < len(mods) and not self.training \
+                    and isinstance(mods[i + 1], nn.BatchNorm1d) and not isinstance(mods[i + 1], NarrowBatchNorm1d):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                y = ops.linear_bn_act_eval(x, m, mods[i + 1], relu)
+                if y is not None:
+                    x = y
+                    i += 3 if relu else 2
+                    continue
             # SyncBatchNorm (convert_sync_batchnorm, tools/train.py:246-247) takes the same fused pass: ops.batch_norm_act
             # synchronises its statistics over the ranks; 6 / 8-channel inputs do not fit it and stay on torch's module
             if isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and not isinstance(m, NarrowBatchNorm1d) \

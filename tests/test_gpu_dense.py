@@ -317,3 +317,83 @@ def test_row_streaming_linear_is_bit_identical_to_the_gather_gemm_case(m, cin, c
         if addend is not None:
             ref = ref * add.double() if mul else ref + add.double()
         assert float((new.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("m,cin,cout", [(174633, 128, 256), (70001, 256, 64), (5000, 64, 128), (4099, 96, 256), (257, 256, 128),
+                                        (255, 64, 64), (1, 32, 64), (20000, 128, 64)])
+def test_six_product_linear_is_fp32_grade(m, cin, cout):
+    """The per-point MLPs' forward (csrc/linear_x6.hip): operands split three ways into bf16, six bf16 MFMAs per product.
+    Against float64 its error is that of an fp32 evaluation -- the same grade as the v_mfma_f32_16x16x4_f32 kernel it
+    replaces and two orders of magnitude under the three-product split -- with operand magnitudes spread over six decades
+    (the split is exact whatever the exponent); the eval epilogue (column scale / shift, ReLU) rounds as the separate pass does."""
+    from openseg3d_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(m + 3 * cin + cout)
+    x = (torch.randn(m, cin, generator=gen) * torch.logspace(-3, 3, cin)[None, :]).to(dev)
+    w = (torch.randn(cout, cin, generator=gen) / cin ** 0.5).to(dev)
+    b = torch.randn(cout, generator=gen).to(dev)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    mag = (x.double().abs() @ w.double().abs().t()) + b.double().abs()  # what the rounding errors scale with
+
+    packed = torch.empty((_lib.query("seg3d_linear_packed_bytes_x6", cin, cout),), dtype=torch.uint8, device=dev)
+    _lib.call("seg3d_linear_pack_weight_x6", ops._ptr(w), cin, cout, 0, ops._ptr(packed), ops._stream())
+    y6 = ops._linear_apply_x6(x, packed, b, cin, cout)
+    y32 = ops._linear_apply_f32(x, ops._linear_pack_f32(w, 0), b, cin, cout) if cout % 16 == 0 and cin % 16 == 0 else None
+    y3 = ops._linear_apply(x, ops._linear_pack(w, False), b, cin, cout)
+    e6 = float(((y6.double() - ref).abs() / mag).max())
+    e3 = float(((y3.double() - ref).abs() / mag).max())
+    assert e6 < 1e-6, e6  # fp32 grade: a few 2^-24 of the sum of magnitudes
+    assert e3 > 10 * e6, (e3, e6)  # (the three-product split sits at 2^-16)
+    if y32 is not None:
+        e32 = float(((y32.double() - ref).abs() / mag).max())
+        assert e6 < 4 * e32 + 1e-8, (e6, e32)
+    # through ops.linear(exact=True), the route of the per-point MLPs
+    assert ops._x6_fits(cin, cout)
+    with torch.no_grad():
+        via = ops.linear(x, torch.nn.Parameter(w), torch.nn.Parameter(b), exact=True)
+    assert torch.equal(via, y6)
+    # eval epilogue: y * scale + shift, ReLU -- bit for bit the separate passes
+    s = (torch.rand(cout, generator=gen) + 0.5).to(dev)
+    t = torch.randn(cout, generator=gen).to(dev)
+    plain = ops._linear_apply_x6(x, packed, None, cin, cout)
+    fused = ops._linear_apply_x6(x, packed, None, cin, cout, scale=s, shift=t, relu=True)
+    assert torch.equal(fused, torch.relu(plain * s + t))
+    # the transposed pack reads W^T: same stream as packing the materialised transpose
+    if cin % 64 == 0 and cout % 32 == 0:
+        pt = torch.empty((_lib.query("seg3d_linear_packed_bytes_x6", cout, cin),), dtype=torch.uint8, device=dev)
+        pm = torch.empty_like(pt)
+        _lib.call("seg3d_linear_pack_weight_x6", ops._ptr(w), cout, cin, 1, ops._ptr(pt), ops._stream())
+        wt = w.t().contiguous()
+        _lib.call("seg3d_linear_pack_weight_x6", ops._ptr(wt), cout, cin, 0, ops._ptr(pm), ops._stream())
+        assert torch.equal(pt, pm)
+
+
+def test_eval_point_mlp_runs_linear_batchnorm_relu_as_one_launch():
+    """FusedMLP in eval mode hands Linear -> BatchNorm1d -> ReLU to the six-product kernel's epilogue: bit-identical to the
+    Linear followed by the folded-affine pass, and the training-mode forward (batch statistics) is untouched."""
+    from openseg3d_amd import ops, segformer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    mlp = segformer._bn_mlp([96, 256, 128, 64]).to(dev)
+    for mod in mlp.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.normal_()
+            mod.running_var.uniform_(0.5, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_()
+    x = torch.randn(30011, 96, device=dev)
+    mlp.eval()
+    with torch.no_grad():
+        fused = mlp(x)
+        ref = x
+        mods = list(mlp)
+        for i in range(0, len(mods), 3):
+            ref = ops.batch_norm_act(ops.linear(ref, mods[i].weight, None, exact=True), mods[i + 1], relu=True)
+    assert torch.equal(fused, ref)
+    import copy
+    want = torch.nn.Sequential(*[copy.deepcopy(m) for m in mlp]).double().eval()(x.double())
+    assert float((fused.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    mlp.train()
+    y = mlp(x.requires_grad_())
+    y.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
