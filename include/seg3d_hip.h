@@ -374,8 +374,10 @@ int seg3d_linear_fwd_mul(const float* x, int64_t m, const void* w_packed, const 
  *   tok      voxel rows grouped by window (ascending window id, ascending row inside)
  *   win_start/win_count [<= min(m, canvas)]  CSR of the non-empty windows into tok
  *   win_tile0 [<= min(m, canvas)]  first 32-token tile of each window in the 32-padded token space
- *   tile_item [<= m/32 + windows][2]  (window, 32-token tile) work items of the attention kernels
- *   qg_item   [<= m/16 + windows][2]  (window, 128-query chunk = 4 tiles) work items of the wide-head attention forward
+ *   tile_item [<= m/32 + windows][4]  {window, 32-token tile, win_start, win_count}: work items of the attention kernels, each
+ *                                     a whole descriptor (one 16-byte read; no dependent win_start / win_count reads in front
+ *                                     of a workgroup's first gather)
+ *   qg_item   [<= m/16 + windows][4]  {window, 128-token chunk = 4 tiles, win_start, win_count}: items of the wide-head kernels
  *   counts   device int32[4]: {non-empty windows, voxels with slot == -1, 32-token tiles, 128-query chunks}
  */
 size_t seg3d_window_partition_workspace_bytes(int64_t m, int32_t batch_size, const int32_t* nwin_xyz);

@@ -88,7 +88,7 @@ template <int DH, bool DROPOUT>
 __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-    const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min,
+    const int4* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min,
     float* __restrict__ out, float* __restrict__ lse, DropoutParams drop, int xcd_groups, int xcd_block) {
     using C = Cfg<DH>;
     using F = FwdGeo<DH>;
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
         if (tid < count && j0 + tid < J) {
             int item_i, hg_i;
             unit_of(j0 + tid, &item_i, &hg_i);
-            const int2 it = items[item_i];
-            desc[(j0 + tid) & (kDescRing - 1)] = make_int4(win_start[it.x], win_count[it.x], it.y, it.x);
+            const int4 it = items[item_i];  // {window, tile / chunk, first token slot, tokens}: no dependent win_start / win_count reads
+            desc[(j0 + tid) & (kDescRing - 1)] = make_int4(it.z, it.w, it.y, it.x);
         }
     };
 
@@ -575,11 +575,11 @@ __global__ __launch_bounds__(256, FwdGeo<DH>::waves(DROPOUT)) void attn_fused_fw
 
 template <int DH>
 int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const int32_t* tok,
-           const int32_t* win_start, const int32_t* win_count, const int2* tile_item, int n_tiles, const int2* chunk_item,
+           const int32_t* win_start, const int32_t* win_count, const int4* tile_item, int n_tiles, const int4* chunk_item,
            int n_chunks, int heads, const float* tau, float tau_min, float* out, float* lse, const DropoutParams& drop,
            hipStream_t st) {
     using C = Cfg<DH>;
-    const int2* items = C::kNarrow ? tile_item : chunk_item;
+    const int4* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
     // one round of resident workgroups (persistent): CUs x workgroups per CU, or fewer when there is less work
     static const int n_cu = [] {
@@ -622,8 +622,8 @@ int attn_fused_fwd_launch(const float* q, const float* k, const float* v, int ld
                           const int32_t* chunk_item, int n_chunks, int heads, int dh, const float* tau, float tau_min,
                           float* out, float* lse, float dropout_p, uint64_t seed, hipStream_t st) {
     const DropoutParams drop = make_dropout(dropout_p, seed);
-    const int2* ti = reinterpret_cast<const int2*>(tile_item);
-    const int2* ci = reinterpret_cast<const int2*>(chunk_item);
+    const int4* ti = reinterpret_cast<const int4*>(tile_item);
+    const int4* ci = reinterpret_cast<const int4*>(chunk_item);
     switch (dh) {
         case 6: return launch<6>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, ti, n_tiles, ci, n_chunks, heads, tau, tau_min, out, lse, drop, st);
         case 12: return launch<12>(q, k, v, ldq, ldk, ldv, tok, win_start, win_count, ti, n_tiles, ci, n_chunks, heads, tau, tau_min, out, lse, drop, st);

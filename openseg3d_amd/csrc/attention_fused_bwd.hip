@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int ldq, int ldk, int ldv,
     const float* __restrict__ out, const float* __restrict__ dout, const float* __restrict__ lse,
     const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-    const int2* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
+    const int4* __restrict__ items, int n_items, int heads, const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
     int lddq, float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, float* __restrict__ tau_part,
     float* __restrict__ delta_buf, DropoutParams drop, int xcd_block) {
     using C = Cfg<DH>;
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256, (kBwdWaves<DH, MODE>)) void attn_fused_bwd(
         if (MODE == 0 && tau_part && lane == 0) tau_part[(size_t)blockIdx.x * 4 + wave] = 0.f;
         return;
     }
-    const int2 item = items[item_i];
-    const int n = win_count[item.x], start = win_start[item.x];
+    const int4 item = items[item_i];  // {window, tile / chunk, first token slot, tokens}: one round trip less in front of the gathers
+    const int n = item.w, start = item.z;
     const int n_t = (n + 31) >> 5;  // 32-token tiles of the window (streamed and stationary alike)
     const int h0 = (gu % hgn) * HG;
     const int c_all = heads * DH;
@@ -791,12 +791,12 @@ static size_t bwd_blocks(int n_items, int hgn, int xb) {
 
 template <int DH>
 int launch(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out, const float* dout,
-           const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count, const int2* tile_item,
-           int n_tiles, const int2* chunk_item, int n_chunks, int heads, const float* tau, float tau_min, float* dq, float* dk,
+           const float* lse, const int32_t* tok, const int32_t* win_start, const int32_t* win_count, const int4* tile_item,
+           int n_tiles, const int4* chunk_item, int n_chunks, int heads, const float* tau, float tau_min, float* dq, float* dk,
            float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part, float* delta_buf, const DropoutParams& drop,
            hipStream_t st) {
     using C = Cfg<DH>;
-    const int2* items = C::kNarrow ? tile_item : chunk_item;
+    const int4* items = C::kNarrow ? tile_item : chunk_item;
     const int n_items = C::kNarrow ? n_tiles : n_chunks;
     const int xb = xcd_block_items(C::kNarrow, n_items);
     const dim3 grid((unsigned)(bwd_blocks(n_items, heads / C::HG, xb)));
@@ -838,8 +838,8 @@ int attn_fused_bwd_launch(const float* q, const float* k, const float* v, int ld
                           float* dv, int lddq, int lddk, int lddv, float* dtau, void* workspace, const DropoutParams& drop,
                           hipStream_t st) {
     (void)m;
-    const int2* ti = reinterpret_cast<const int2*>(tile_item);
-    const int2* ci = reinterpret_cast<const int2*>(chunk_item);
+    const int4* ti = reinterpret_cast<const int4*>(tile_item);
+    const int4* ci = reinterpret_cast<const int4*>(chunk_item);
     float* tau_part = static_cast<float*>(workspace);
     float* delta_buf = reinterpret_cast<float*>(static_cast<char*>(workspace) + tau_part_bytes(n_tiles, n_chunks, heads, dh));
 #define SEG3D_FB(D)                                                                                                        \

@@ -122,7 +122,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 8) void attn_small_fwd(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, int ldq, int ldk, int ldv,
                                                       const int32_t* __restrict__ tok, const int32_t* __restrict__ win_start,
-                                                      const int32_t* __restrict__ win_count, const int2* __restrict__ tile_item,
+                                                      const int32_t* __restrict__ win_count, const int4* __restrict__ tile_item,
                                                       int heads, const float* __restrict__ tau, float tau_min,
                                                       float* __restrict__ out, float* __restrict__ lse, DropoutParams drop) {
     extern __shared__ float smem[];
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256, 8) void attn_small_fwd(const float* __restrict
     float* kbuf = smem;
     float* vbuf = smem + kTile * c;
     const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
-    const int2 item = tile_item[blockIdx.x];
-    const int n = win_count[item.x], start = win_start[item.x];
+    const int4 item = tile_item[blockIdx.x];
+    const int n = item.w, start = item.z;
     const int qi = item.y * kTile + i;
     const int32_t qtok = qi < n ? tok[start + qi] : -1;
     const float tau_c = fmaxf(tau[0], tau_min);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
                                                         const float* __restrict__ out, const float* __restrict__ dout,
                                                         const float* __restrict__ lse, const int32_t* __restrict__ tok,
                                                         const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-                                                        const int2* __restrict__ tile_item, int heads,
+                                                        const int4* __restrict__ tile_item, int heads,
                                                         const float* __restrict__ tau, float tau_min, float* __restrict__ dq,
                                                         int lddq, float* __restrict__ tau_part, DropoutParams drop) {
     extern __shared__ float smem[];
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void attn_small_bwd_q(const float* __restri
     float* vbuf = smem + kTile * c;
     __shared__ float tau_red[8];
     const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
-    const int2 item = tile_item[blockIdx.x];
-    const int n = win_count[item.x], start = win_start[item.x];
+    const int4 item = tile_item[blockIdx.x];
+    const int n = item.w, start = item.z;
     const int qi = item.y * kTile + i;
     const int32_t qtok = qi < n ? tok[start + qi] : -1;
     const float tau_c = fmaxf(tau[0], tau_min);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
                                                          const float* __restrict__ out, const float* __restrict__ dout,
                                                          const float* __restrict__ lse, const int32_t* __restrict__ tok,
                                                          const int32_t* __restrict__ win_start, const int32_t* __restrict__ win_count,
-                                                         const int2* __restrict__ tile_item, int heads,
+                                                         const int4* __restrict__ tile_item, int heads,
                                                          const float* __restrict__ tau, float tau_min, float* __restrict__ dk,
                                                          int lddk, float* __restrict__ dv, int lddv, DropoutParams drop) {
     extern __shared__ float smem[];  // q~ [32][c], dO [32][c], (L, delta) [32][heads][2]
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256, 3) void attn_small_bwd_kv(const float* __restr
     float* gbuf = smem + kTile * c;
     float* lbuf = smem + 2 * kTile * c;
     const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
-    const int2 item = tile_item[blockIdx.x];
-    const int n = win_count[item.x], start = win_start[item.x];
+    const int4 item = tile_item[blockIdx.x];
+    const int n = item.w, start = item.z;
     const int kj = item.y * kTile + i;
     const int32_t ktok = kj < n ? tok[start + kj] : -1;
     const float tau_c = fmaxf(tau[0], tau_min);
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024) void tau_reduce_small(const float* __restrict
 template <int DH>
 int run_small_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* out,
                   const float* dout, const float* lse, const int32_t* tok, const int32_t* win_start,
-                  const int32_t* win_count, const int2* tile_item, int n_tiles, int heads, const float* tau, float tau_min,
+                  const int32_t* win_count, const int4* tile_item, int n_tiles, int heads, const float* tau, float tau_min,
                   float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, float* dtau, float* tau_part,
                   const DropoutParams& drop, hipStream_t st) {
     const size_t smem_q = (size_t)2 * kTile * heads * DH * sizeof(float);
@@ -437,7 +437,7 @@ int attn_small_fwd_launch(const float* q, const float* k, const float* v, int ld
     if (dh != 6) return SEG3D_EINVAL;
     const size_t smem = (size_t)2 * kTile * heads * 6 * sizeof(float);
     hipLaunchKernelGGL(attn_small_fwd<6>, dim3((unsigned)n_tiles), dim3(32 * heads), smem, st, q, k, v, ldq, ldk, ldv, tok,
-                       win_start, win_count, reinterpret_cast<const int2*>(tile_item), heads, tau, tau_min, out, lse, drop);
+                       win_start, win_count, reinterpret_cast<const int4*>(tile_item), heads, tau, tau_min, out, lse, drop);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;
 }
@@ -451,7 +451,7 @@ int attn_small_bwd_launch(const float* q, const float* k, const float* v, int ld
                           const float* tau, float tau_min, float* dq, float* dk, float* dv, int lddq, int lddk, int lddv,
                           float* dtau, void* workspace, const DropoutParams& drop, hipStream_t st) {
     if (dh != 6) return SEG3D_EINVAL;
-    const int2* ti = reinterpret_cast<const int2*>(tile_item);
+    const int4* ti = reinterpret_cast<const int4*>(tile_item);
     float* tau_part = static_cast<float*>(workspace);  // n_tiles floats
     return run_small_bwd<6>(q, k, v, ldq, ldk, ldv, out, dout, lse, tok, win_start, win_count, ti, n_tiles, heads, tau,
                             tau_min, dq, dk, dv, lddq, lddk, lddv, dtau, tau_part, drop, st);

@@ -103,8 +103,8 @@ __global__ __launch_bounds__(kThreads) void win_geom_flags(const uint32_t* __res
 __global__ __launch_bounds__(kThreads) void win_compact(const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs,
                                                         const uint4* __restrict__ geom_prefix, int64_t n_canvas,
                                                         int32_t* __restrict__ win_start, int32_t* __restrict__ win_count,
-                                                        int32_t* __restrict__ win_tile0, int2* __restrict__ tile_item,
-                                                        int2* __restrict__ qg_item, int32_t* __restrict__ counts) {
+                                                        int32_t* __restrict__ win_tile0, int4* __restrict__ tile_item,
+                                                        int4* __restrict__ qg_item, int32_t* __restrict__ counts) {
     const int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (w >= n_canvas) return;
     const uint32_t n = count[w];
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(kThreads) void win_compact(const uint32_t* __restri
         win_count[cw] = (int32_t)n;
         if (win_tile0) win_tile0[cw] = (int32_t)p.y;
         if (tile_item)
-            for (uint32_t t = 0; t < ((n + 31u) >> 5); ++t) tile_item[p.y + t] = make_int2((int)cw, (int)t);
+            for (uint32_t t = 0; t < ((n + 31u) >> 5); ++t) tile_item[p.y + t] = make_int4((int)cw, (int)t, (int)offs[w], (int)n);
         if (qg_item)
-            for (uint32_t q = 0; q < ((n + 127u) >> 7); ++q) qg_item[p.z + q] = make_int2((int)cw, (int)q);
+            for (uint32_t q = 0; q < ((n + 127u) >> 7); ++q) qg_item[p.z + q] = make_int4((int)cw, (int)q, (int)offs[w], (int)n);
     }
     if (w == n_canvas - 1) {
         counts[0] = (int32_t)(cw + (n ? 1u : 0u));
@@ -228,7 +228,7 @@ int seg3d_window_partition(const int32_t* coords, int64_t m, int32_t batch_size,
     rc = scan_exclusive_u32x4(geom, geom, (int64_t)nc, nullptr, lvl_tmp, st);
     if (rc != SEG3D_OK) return rc;
     hipLaunchKernelGGL(win_compact, dim3(nbc), dim3(kThreads), 0, st, count, offs, geom, (int64_t)nc, win_start,
-                       win_count, win_tile0, reinterpret_cast<int2*>(tile_item), reinterpret_cast<int2*>(qg_item),
+                       win_count, win_tile0, reinterpret_cast<int4*>(tile_item), reinterpret_cast<int4*>(qg_item),
                        counts);
     SEG3D_CHECK_LAUNCH();
     return SEG3D_OK;

@@ -1578,8 +1578,8 @@ def window_partition(coords, batch_size, window_shape, nwin_xyz, shift_xyz, leve
     wi.win_start = torch.empty((cap,), **i32)
     wi.win_count = torch.empty((cap,), **i32)
     wi.win_tile0 = torch.empty((cap,), **i32)
-    wi.tile_item = torch.empty((m // 32 + cap + 1, 2), **i32)
-    wi.qg_item = torch.empty((m // 16 + cap + 1, 2), **i32)
+    wi.tile_item = torch.empty((m // 32 + cap + 1, 4), **i32)  # {window, tile, first token slot, tokens}
+    wi.qg_item = torch.empty((m // 16 + cap + 1, 4), **i32)
     wi.counts = torch.zeros((4,), **i32)
     nl = len(levels)
     arr = ctypes.c_int32 * nl
