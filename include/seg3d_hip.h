@@ -293,6 +293,10 @@ int seg3d_linear_wgrad_partials(const float* x, const float* dy, int64_t m, int3
 int seg3d_linear_wgrad_partials_xbf16(const uint16_t* x_bf16, const float* dy, int64_t m, int32_t cin, int32_t cout,
                                       int32_t with_bias, void* workspace, size_t workspace_bytes, int32_t* chunks,
                                       void* stream);
+/* A/B switch of the LDS-shared dense weight-gradient kernel (openseg3d_amd/csrc/wgrad_dense_lds.hip; OFF by default, it did
+ * not win): 1 = on, 0 = off, -1 = SEG3D_WGRAD_LDS's choice.  Takes cout % 192 == 0, cin % 96 == 0, m >= 4096; the workspace
+ * query covers both kernels. */
+int seg3d_debug_set_wgrad_lds(int32_t on);
 int seg3d_reduce_partials(const float* part, int32_t chunks, int64_t n, int64_t nw, float* dw, float* db, void* stream);
 int seg3d_reduce_partials_batched(const void* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
 /* a6  exact-fp32 variant for the per-point MLPs (segformer.py:21-32,58-76), whose split-bf16 forward error would land

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "seg3d_hip.h")
 
 OK, EINVAL, EWORKSPACE, ELAUNCH = 0, -1, -2, -3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 _p, _i32, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 _u64 = ctypes.c_uint64
@@ -63,6 +63,7 @@ SIGNATURES = {
     "seg3d_linear_packed_bytes_f32": (ctypes.c_size_t, [_i32, _i32]),
     "seg3d_linear_pack_weight_f32": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd_f32": (ctypes.c_int, [_p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "seg3d_debug_set_wgrad_lds": (ctypes.c_int, [_i32]),
     "seg3d_linear_packed_bytes_x6": (ctypes.c_size_t, [_i32, _i32]),
     "seg3d_linear_pack_weight_x6": (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "seg3d_linear_fwd_x6": (ctypes.c_int, [_p, _i64, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),

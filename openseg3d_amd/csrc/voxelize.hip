@@ -298,7 +298,7 @@ int seg3d_cart2polar_f64(const double* points, int64_t n_points, int32_t row_str
     return cart2polar_impl<double>(points, n_points, row_stride, xyz_col, out, stream);
 }
 
-int seg3d_abi_version(void) { return 39; }
+int seg3d_abi_version(void) { return 40; }
 
 namespace {
 thread_local char g_last_error[320] = "";

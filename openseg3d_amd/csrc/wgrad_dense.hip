@@ -23,6 +23,11 @@
 
 #include "attn_common.hpp"
 
+// wgrad_dense_lds.hip: the LDS-shared form for cout % 96 == 0, cin % 48 == 0 (1 = it takes the shape)
+int wgrad_dense_lds_plan(int64_t m, int cin, int cout, int* chunks, int64_t* rows);
+int wgrad_dense_lds_launch(const float* x, const float* dy, int64_t m, int cin, int cout, int chunks, int64_t rows, float* part,
+                           int want_bias, hipStream_t st);
+
 namespace {
 
 using namespace attn;
@@ -35,6 +40,7 @@ struct Plan {
     int chunks;    // row chunks (partial sums)
     int64_t rows;  // rows per chunk (multiple of 32)
     int group;     // 0 = the waves of a workgroup split the rows of one block; else QB << 4 | QC blocks per workgroup
+    int lds;       // 1 = the LDS-shared kernel of wgrad_dense_lds.hip (fp32 rows only)
 };
 
 // SEG3D_WGRAD_GROUP=1 (A/B, OFF by default: it lost).  Measured (tools/wgrad_bench.py, one box, split-K -> groups): 96 -> 192
@@ -47,9 +53,19 @@ static const bool g_wgrad_group = [] {
     return e && atoi(e) == 1;
 }();
 
-Plan plan(int64_t m, int cin, int cout) {
-    Plan p{(cout + 63) / 64, (cin + 63) / 64, 0, 32, 0};
+Plan plan(int64_t m, int cin, int cout, bool allow_lds = false) {
+    Plan p{(cout + 63) / 64, (cin + 63) / 64, 0, 32, 0, 0};
     if (m <= 0) return p;
+    if (allow_lds) {
+        int c = 0;
+        int64_t r = 0;
+        if (wgrad_dense_lds_plan(m, cin, cout, &c, &r)) {
+            p.chunks = c;
+            p.rows = r;
+            p.lds = 1;
+            return p;
+        }
+    }
     if (g_wgrad_group && p.nbo * p.nbi >= 4 && m >= 8192) {
         // the block group with the fewest operand slabs per block among the shapes that divide the block grid; at least three waves
         int best_b = 0, best_c = 0;
@@ -389,8 +405,8 @@ int wgrad_chunk_reduce(const float* part, int chunks, int64_t n, int64_t nw, flo
 
 extern "C" size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int32_t cout) {
     if (m < 0 || cin <= 0 || cout <= 0) return 0;
-    const Plan p = plan(m, cin, cout);
-    return ((size_t)p.chunks * ((size_t)cin * cout + cout) + 64) * sizeof(float);
+    const Plan p = plan(m, cin, cout), q = plan(m, cin, cout, true);  // either kernel may run (bf16 rows take the first)
+    return ((size_t)(p.chunks > q.chunks ? p.chunks : q.chunks) * ((size_t)cin * cout + cout) + 64) * sizeof(float);
 }
 
 // The two halves of seg3d_linear_wgrad apart: partial blocks now, their fixed-order sum later (alone, or batched with the
@@ -398,6 +414,10 @@ extern "C" size_t seg3d_linear_wgrad_workspace_bytes(int64_t m, int32_t cin, int
 // one launch of the partial-block kernel for plan p
 static void launch_dense(const Plan& p, const void* x, bool x_bf16, const float* dy, int64_t m, int cin, int cout, float* part,
                          int want_bias, hipStream_t st) {
+    if (p.lds) {
+        wgrad_dense_lds_launch(static_cast<const float*>(x), dy, m, cin, cout, p.chunks, p.rows, part, want_bias, st);
+        return;
+    }
     if (p.group) {
         const int qb = p.group >> 4, qc = p.group & 15;
         const int nbi_g = p.nbi / qc, groups = (p.nbo / qb) * nbi_g;
@@ -427,7 +447,7 @@ static int linear_wgrad_partials(const void* x, bool x_bf16, const float* dy, in
     if (workspace_bytes < seg3d_linear_wgrad_workspace_bytes(m, cin, cout) || (m > 0 && !workspace)) return SEG3D_EINVAL;
     *chunks = 0;
     if (m == 0) return SEG3D_OK;
-    const Plan p = plan(m, cin, cout);
+    const Plan p = plan(m, cin, cout, !x_bf16);
     launch_dense(p, x, x_bf16, dy, m, cin, cout, static_cast<float*>(workspace), with_bias ? 1 : 0, as_stream(stream));
     SEG3D_CHECK_LAUNCH();
     *chunks = p.chunks;
@@ -467,7 +487,7 @@ extern "C" int seg3d_linear_wgrad(const float* x, const float* dy, int64_t m, in
     if (m > 0 && (!x || !dy)) return SEG3D_EINVAL;
     if (workspace_bytes < seg3d_linear_wgrad_workspace_bytes(m, cin, cout) || (m > 0 && !workspace)) return SEG3D_EINVAL;
     hipStream_t st = as_stream(stream);
-    const Plan p = plan(m, cin, cout);
+    const Plan p = plan(m, cin, cout, true);
     float* part = static_cast<float*>(workspace);
     if (m > 0) {
         launch_dense(p, x, false, dy, m, cin, cout, part, db ? 1 : 0, st);

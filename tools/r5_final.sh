@@ -9,6 +9,7 @@ python bench.py --mode fwd --steps 20 --warmup 5 --no-cpu-baseline > $O/fwd.json
 SEG3D_WGRAD_CENTER_FIRST=0 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/no_centre_first.json 2> $O/no_centre_first.err; echo no_centre_first rc=$?
 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/default_b.json 2> $O/default_b.err; echo default_b rc=$?
 SEG3D_WGRAD_DEFER=0 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/nodefer.json 2> $O/nodefer.err; echo nodefer rc=$?
+SEG3D_POINT_MLP=fp32 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/default_f32mlp.json 2> $O/default_f32mlp.err; echo f32mlp rc=$?
 SEG3D_BENCH_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/ddp1.json 2> $O/ddp1.err; echo ddp1 rc=$?
 SEG3D_DDP_OVERLAP=0 SEG3D_BENCH_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/ddp1_nooverlap.json 2> $O/ddp1_nooverlap.err; echo ddp1_nooverlap rc=$?
 SEG3D_DDP=torch SEG3D_BENCH_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-fp32-exact > $O/ddp1_torch.json 2> $O/ddp1_torch.err; echo ddp1_torch rc=$?
