@@ -133,8 +133,11 @@ __device__ __forceinline__ f32x4 mfma2(const bf16x8& a_hi, const bf16x8& a_lo, c
 // (192 <-> 384: 18 blocks x 128 channel-reads per row = 2 304 -> 6 groups x 256 = 1 536).  No cross-wave sum, no barrier: a wave
 // stores its own block.  Per-wave work is 4 x longer, so the chunks are 2 x shorter (the partial blocks double: still a
 // quarter of the operand bytes).
-template <bool XB, bool GROUP>
-__global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
+// DEPTH (round 5, fp32 rows, split-K form): steps of a wave in flight.  The kernel is bound by its waves' round trips (~3 us per
+// 16 KB step at two waves per SIMD, section 6); a second register set does not fit 256 registers (101 - 223 spills), so the deep
+// form runs ONE wave per SIMD with DEPTH sets of x and dy rows (512 registers).
+template <bool XB, bool GROUP, int DEPTH = 1>
+__global__ __launch_bounds__(kThreads, (DEPTH > 1 ? 1 : 2)) void wgrad_dense_kernel(const void* __restrict__ x_v, const float* __restrict__ dy,
                                                                int64_t m_rows, int cin, int cout, int rows_per_chunk,
                                                                int nbi, int tiles, float* __restrict__ part,
                                                                int want_bias, int group) {
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
     f32x4 db_acc = {0.f, 0.f, 0.f, 0.f};
 
     f32x4 xr[XB ? 1 : 8], yr[8];
+    f32x4 xd[DEPTH > 1 ? DEPTH : 1][8], yd[DEPTH > 1 ? DEPTH : 1][8];  // the register sets of the deep form
     uint2 xq[XB ? 8 : 1];
     bf16x8 b_hi[4], b_lo[XB ? 1 : 4];
     auto load_rows = [&](const float* src, int ld, uint32_t off, int step, f32x4(&dst)[8]) {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)i * ld * 4 + off);
     };
-    auto load_x = [&](int step) {
+    auto load_x = [&](int step, auto& xs) {
         if constexpr (XB) {
             const char* base = static_cast<const char*>(x_v) + (r_begin + 32 * (int64_t)step) * cin * 2;
 #pragma unroll
@@ -186,10 +190,10 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
         } else {
             const char* base = reinterpret_cast<const char*>(x + (r_begin + 32 * (int64_t)step) * cin);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const f32x4*>(base + (size_t)i * cin * 4 + xoff);
+            for (int i = 0; i < 8; ++i) xs[i] = *reinterpret_cast<const f32x4*>(base + (size_t)i * cin * 4 + xoff);
         }
     };
-    auto make_b = [&]() {
+    auto make_b = [&](auto& xs) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if constexpr (XB) {
@@ -197,21 +201,21 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
             } else {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = xr[i][b];
+                for (int i = 0; i < 8; ++i) v[i] = xs[i][b];
                 split_frag(v, &b_hi[b], &b_lo[b]);
             }
         }
     };
-    auto multiply = [&]() {
+    auto multiply = [&](auto& ys) {
         if (want_db) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) db_acc += yr[i];
+            for (int i = 0; i < 8; ++i) db_acc += ys[i];
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = yr[i][a];
+            for (int i = 0; i < 8; ++i) v[i] = ys[i][a];
             bf16x8 a_hi, a_lo;
             split_frag(v, &a_hi, &a_lo);
 #pragma unroll
@@ -226,16 +230,39 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
     const int n_full = (int)((r_end - r_begin) / 32);
     constexpr int kStride = GROUP ? 1 : kWaves;  // GROUP: every wave walks all steps of the chunk
     int s = GROUP ? 0 : wave;
-    if (s < n_full) {
-        load_x(s);
-        load_rows(dy, cout, yoff, s, yr);
-    }
-    for (; s < n_full; s += kStride) {
-        const bool more = s + kStride < n_full;
-        make_b();
-        if (more) load_x(s + kStride);
-        multiply();
-        if (more) load_rows(dy, cout, yoff, s + kStride, yr);
+    if constexpr (DEPTH > 1) {
+        static_assert(!XB && !GROUP, "the deep form is the fp32 split-K form's");
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (s + d * kStride < n_full) {
+                load_x(s + d * kStride, xd[d]);
+                load_rows(dy, cout, yoff, s + d * kStride, yd[d]);
+            }
+        for (; s < n_full; s += DEPTH * kStride) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int cur = s + d * kStride;
+                if (cur < n_full) {  // (wave-uniform)
+                    const bool more = cur + DEPTH * kStride < n_full;
+                    make_b(xd[d]);
+                    if (more) load_x(cur + DEPTH * kStride, xd[d]);
+                    multiply(yd[d]);
+                    if (more) load_rows(dy, cout, yoff, cur + DEPTH * kStride, yd[d]);
+                }
+            }
+        }
+    } else {
+        if (s < n_full) {
+            load_x(s, xr);
+            load_rows(dy, cout, yoff, s, yr);
+        }
+        for (; s < n_full; s += kStride) {
+            const bool more = s + kStride < n_full;
+            make_b(xr);
+            if (more) load_x(s + kStride, xr);
+            multiply(yr);
+            if (more) load_rows(dy, cout, yoff, s + kStride, yr);
+        }
     }
     // the chunk's last, partial step (only the last chunk of the tensor has one): rows clamped and masked
     if ((r_end - r_begin) % 32 != 0 && (GROUP || n_full % kWaves == wave)) {
@@ -255,8 +282,8 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_dense_kernel(const void* __
             }
             yr[i] = ok ? vy : z;
         }
-        make_b();
-        multiply();
+        make_b(xr);
+        multiply(yr);
     }
 
     float* pw = part + (int64_t)chunk * ((int64_t)cout * cin + cout);
@@ -432,6 +459,20 @@ static void launch_dense(const Plan& p, const void* x, bool x_bf16, const float*
     }
     const int tiles = p.nbo * p.nbi;
     const unsigned blocks = (unsigned)((p.chunks + 7) / 8 * 8) * (unsigned)tiles;
+    // SEG3D_WGRAD_DENSE_DEPTH=3 (A/B, OFF: it lost): three steps of a wave in flight at ONE wave per SIMD (fp32 rows; 472
+    // registers; four sets spill).  Measured (tools/wgrad_bench.py --partials, one box): the family 3.46 -> 4.88 ms (192 -> 192
+    // @58 k 27.2 -> 37.1 us, 384 -> 768 @19 k 69.4 -> 91.7); with 256 / 512 workgroups 4.95 / 4.79 ms.  A second set at two
+    // waves per SIMD does not fit (101 - 223 spilled registers).  The kernel needs its second wave per SIMD (the other wave's
+    // conversions under this wave's MFMAs) more than it needs bytes in flight.
+    static const int depth = [] {
+        const char* e = getenv("SEG3D_WGRAD_DENSE_DEPTH");
+        return (e && atoi(e) == 3) ? 3 : 1;
+    }();
+    if (!x_bf16 && depth == 3) {
+        hipLaunchKernelGGL((wgrad_dense_kernel<false, false, 3>), dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows,
+                           p.nbi, tiles, part, want_bias, 0);
+        return;
+    }
     if (x_bf16)
         hipLaunchKernelGGL((wgrad_dense_kernel<true, false>), dim3(blocks), dim3(kThreads), 0, st, x, dy, m, cin, cout, (int)p.rows,
                            p.nbi, tiles, part, want_bias, 0);
