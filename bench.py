@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true",
                     help="skip the child run that times the same step with exact-fp32 products (SEG3D_CONV_PRECISION=fp32)")
+    ap.add_argument("--fp64-oracle", action="store_true",
+                    help="evaluate the float64 oracle on the parity sample of a workload other than the headline one too "
+                         "(the headline workload does it by default)")
     ap.add_argument("--no-fp64-oracle", action="store_true",
                     help="skip the second, float64 evaluation of the CPU oracle on the parity sample (`parity.vs_fp64_oracle`; "
                          "run by default for the headline workload only: it doubles the oracle's time)")
@@ -401,7 +404,7 @@ def main():
         model.eval()
         report, o_res, o_coords, o_ids = cpu_baseline(sample, s_cur, s_img, cfg, ds, model)
         o64 = None
-        if args.workload == "one_sweep" and not args.no_fp64_oracle:
+        if (args.workload == "one_sweep" or args.fp64_oracle) and not args.no_fp64_oracle:
             o64 = cpu_baseline(sample, s_cur, s_img, cfg, ds, model, dtype=torch.float64)[1]
         baseline = (report, parity_report(sample, s_cur, s_img, ds, model, dev, o_res, o_coords, o_ids, o64))
         del o64
