@@ -62,6 +62,17 @@ def test_host_only_entry_points():
     # argument validation happens before anything is enqueued: a null call is rejected, not launched
     assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 0, None, 48, 48, None, None, None) == _lib.EINVAL
     assert _lib.load().seg3d_spconv_fwd(None, None, 10, 10, None, 4, None, 50, 48, None, None, None) == _lib.EINVAL
+    # the six-product Linear (csrc/linear_x6.hip) takes cin % 32 == 0 and cout % 64 == 0 and says so through its size query;
+    # three planes of 8-element fragments per (32-channel step, 16-column tile)
+    assert _lib.query("seg3d_linear_packed_bytes_x6", 128, 256) == (128 // 32) * (256 // 64) * 4 * 3 * 64 * 16 == 128 * 256 * 6
+    assert _lib.query("seg3d_linear_packed_bytes_x6", 96, 256) == 96 * 256 * 6
+    for cin, cout in ((48, 64), (64, 96), (6, 64), (64, 22), (0, 64)):
+        assert _lib.query("seg3d_linear_packed_bytes_x6", cin, cout) == 0
+    assert _lib.load().seg3d_linear_fwd_x6(None, 10, None, None, None, None, 0, 128, 256, None, None) == _lib.EINVAL
+    assert _lib.load().seg3d_linear_fwd_x6(None, 0, None, None, None, None, 0, 128, 256, None, None) == 0  # nothing to do
+    # both weight-gradient kernels fit the workspace the query reports; the opt-in switch validates its argument
+    assert _lib.query("seg3d_linear_wgrad_workspace_bytes", 58453, 192, 192) >= 8 * (192 * 192 + 192) * 4
+    assert _lib.load().seg3d_debug_set_wgrad_lds(2) == _lib.EINVAL and _lib.load().seg3d_debug_set_wgrad_lds(-1) == 0
 
 
 @pytest.mark.parametrize("tag,rng,vs", [("cart", [-72, -72, -2, 72, 72, 4.4], [0.1, 0.1, 0.1]),
