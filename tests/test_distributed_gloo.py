@@ -159,24 +159,27 @@ def _worker(rank, world, port, out):
     assert torch.allclose(m2 / total, allrows.var(0, unbiased=False), rtol=1e-12, atol=1e-12)
     # throughput aggregate: sum of units over max of time
     t, u = D.aggregate_throughput(1.0 + rank, 100.0 * (rank + 1), torch.device("cpu"))
-    assert (t, u) == (2.0, 300.0)
+    assert (t, u) == (float(world), 50.0 * world * (world + 1))  # slowest rank's time, all ranks' units
     dist.barrier()
     dist.destroy_process_group()
     out.put(rank)
 
 
 @pytest.mark.timeout(300)
-def test_world_size_2_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_world_size_2_gloo(world):
+    """(world 4: an arena in arrival order, slices closed in order and rank 0's order broadcast with more than one peer --
+    what the 4- and 8-GPU runs of bench.py exercise over RCCL.)"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(240)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(out.get(timeout=5) for _ in procs) == [0, 1]
+    assert sorted(out.get(timeout=5) for _ in procs) == list(range(world))
 
 
 _CHILD = """
